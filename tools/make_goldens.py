@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own functions on CPU.
+
+Runs only in the build container (needs /root/reference); the GPU box and the tests only read
+the committed .npz files.  Nothing from the reference is copied: its modules are imported,
+called on seeded synthetic inputs with formula weights (oracle/weights.py), and the outputs
+are stored.  Harness-side monkeypatches: ``.cuda()`` -> identity (utils_my.py:58,64-65,...
+hard-code it), ``np.random.shuffle`` / ``np.random.randint`` -> injected values, so that the
+random choices of utils_my.py:97 and cn3d_data_load.py:305 are recorded in the fixture.
+
+    python tools/make_goldens.py            # rewrites tests/golden/
+"""
+import argparse
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/training_code"
+sys.path.insert(0, REF)
+
+torch.Tensor.cuda = lambda self, *a, **k: self            # noqa: E731  (harness-side only)
+torch.nn.Module.cuda = lambda self, *a, **k: self         # noqa: E731
+
+import utils_my as R_utils                                  # noqa: E402  reference
+import cn3d_model_conbag as R_model                         # noqa: E402  reference
+import cn3d_data_load as R_load                             # noqa: E402  reference
+
+from oracle.weights import formula_state_dict               # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def canon_groups(xt_MDSK):
+    """(M,D,S,K) reference tensor -> (M,S,K,D) numpy with the K axis sorted lexicographically
+    (torch.topk(sorted=False) leaves the order inside a group unspecified)."""
+    a = xt_MDSK.permute(0, 2, 3, 1).contiguous().numpy()
+    M, S, K, D = a.shape
+    flat = a.reshape(M * S, K, D)
+    out = np.empty_like(flat)
+    for i in range(flat.shape[0]):
+        keys = tuple(flat[i, :, d] for d in reversed(range(D)))
+        out[i] = flat[i][np.lexsort(keys)]
+    return out.reshape(M, S, K, D)
+
+
+def ref_opt(B, N, S, K, D):
+    return SimpleNamespace(temperal_num=3, knn_K=K, ball_radius=0.16, ball_radius2=0.25,
+                           sample_num_level1=S, sample_num_level2=S, INPUT_FEATURE_NUM=D,
+                           Num_Class=512, batchSize=B, pooling="concatenation", SAMPLE_NUM=N)
+
+
+def synth_points(B, G, N, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(B, G, N, D, generator=g) - 0.5
+    return pts.permute(1, 0, 2, 3).reshape(-1, N, D).contiguous()     # cn3d_train_motion_GL.py:226
+
+
+def make_fps():
+    out = {}
+    rng = np.random.RandomState(7)
+    orig = np.random.randint
+    for N in (512, 2048):
+        pcs = (rng.rand(4, N, 3) - 0.5)
+        starts = rng.randint(0, N, size=4)
+        for dt in (np.float64, np.float32):
+            idxs = []
+            for c in range(4):
+                np.random.randint = lambda lo, hi=None, size=None, _s=int(starts[c]): _s
+                try:
+                    idxs.append(R_load.farthest_point_sampling_fast(pcs[c].astype(dt), 64).ravel())
+                finally:
+                    np.random.randint = orig
+            out[f"idx_N{N}_{np.dtype(dt).name}"] = np.stack(idxs).astype(np.int32)
+        out[f"pc_N{N}"] = pcs.astype(np.float64)
+        out[f"start_N{N}"] = starts.astype(np.int32)
+    # reorder (fps_sample_data, cn3d_data_load.py:287-298 is 2-level; data_set.py:665-672 1-level is
+    # restated by the oracle and checked through the 2-level golden with NUM_POINT patched)
+    N = 512
+    pts = (rng.rand(2, N, 4) - 0.5)
+    s1 = rng.randint(0, N, size=2)
+    s2 = rng.randint(0, 64, size=2)
+    R_load.NUM_POINT = N
+    seq = []
+    for c in range(2):
+        seq += [int(s1[c]), int(s2[c])]
+    it = iter(seq)
+    np.random.randint = lambda lo, hi=None, size=None: next(it)
+    try:
+        re = R_load.fps_sample_data(pts.copy(), 64, 16)
+    finally:
+        np.random.randint = orig
+    out["reorder_in"] = pts
+    out["reorder_s1"] = s1.astype(np.int32)
+    out["reorder_s2"] = s2.astype(np.int32)
+    out["reorder_out"] = re
+    np.savez_compressed(os.path.join(OUT, "fps.npz"), **out)
+    print("fps.npz", {k: v.shape for k, v in out.items()})
+
+
+def make_tiny():
+    B, G, N, S, K, D = 2, 3, 128, 16, 8, 4
+    pts = synth_points(B, G, N, D, seed=11)
+    out = {"points": pts.numpy()}
+    xt, yt = R_utils.group_points_3DV_2048(pts.clone(), K, S, SAMPLE_NUM=N)       # r2 = 0.16
+    out["xt_r016"] = canon_groups(xt)
+    out["yt_r016"] = yt.contiguous().numpy()
+    opt = ref_opt(B, N, S, K, D)
+    xt, yt = R_utils.group_points_3DV_nums(pts.clone(), opt, S, K)               # r2 = 0.06
+    out["xt_r006"] = canon_groups(xt)
+    out["yt_r006"] = yt.contiguous().numpy()
+    # encoder on the tiny grouping (train mode)
+    sd = formula_state_dict(D)
+    net = R_model.PointNet_Plus_fine(opt, gost=G, sample_num_level1=S, knn_K=K)
+    net.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    net.train()
+    x, code, x_nor, x_global = net(xt, yt, 1)
+    out.update(x=x.detach().numpy(), code=code.detach().numpy(), x_nor=x_nor.detach().numpy(),
+               x_global=x_global.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "tiny.npz"), **out)
+    print("tiny.npz ok")
+
+
+def run_c1(D, neg_gamma, tag):
+    B, G, N, S, K = 4, 8, 512, 64, 64
+    pts = synth_points(B, G, N, D, seed=100 + D)
+    opt = ref_opt(B, N, S, K, D)
+    out = {"points": pts.numpy(), "meta": np.array([B, G, N, S, K, D], dtype=np.int32)}
+    xt, yt = R_utils.group_points_3DV(pts.clone(), opt)                          # r2 = 0.06
+    assert opt.knn_K == 64 and abs(opt.ball_radius - 0.06) < 1e-12
+    xt_c = canon_groups(xt)
+    out["xt_sum"] = xt_c.sum(axis=2)                                             # (M,S,D) compact check
+    out["xt_first8"] = xt_c[:8]
+    out["yt"] = yt.contiguous().numpy()
+    sd = formula_state_dict(D, neg_gamma=neg_gamma)
+    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
+
+    crit = torch.nn.CrossEntropyLoss()
+    order = np.array([3, 0, 6, 1, 7, 5, 2, 4])
+    out["order"] = order
+    orig_shuffle = np.random.shuffle
+
+    def patched(a):
+        a[:] = order
+
+    # --- eval-mode forward
+    net = R_model.PointNet_Plus_fine(opt, gost=G, sample_num_level1=S, knn_K=K)
+    net.load_state_dict(tsd)
+    net.eval()
+    with torch.no_grad():
+        ev = net(xt, yt, 0)
+    for name, t in zip(("x", "code", "x_nor", "x_global"), ev):
+        out[f"eval_{name}"] = t.numpy()
+
+    # --- train-mode forward + losses + backward + 3 Adam steps (cn3d_train_motion_GL.py:180-181,329-333)
+    net = R_model.PointNet_Plus_fine(opt, gost=G, sample_num_level1=S, knn_K=K)
+    net.load_state_dict(tsd)
+    net.train()
+    taps = {}
+    h1 = net.net3DV_1.register_forward_hook(lambda m, i, o: taps.__setitem__("pooled", o.detach().clone()))
+    h3 = net.net3DV_3.register_forward_hook(lambda m, i, o: taps.__setitem__("local", o.detach().clone()))
+    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
+    sched = torch.optim.lr_scheduler.StepLR(optim, step_size=4, gamma=0.7)
+    losses = []
+    for it in range(3):
+        x, code, x_nor, x_global = net(xt, yt, 1)
+        loss_c = R_utils.global_contrast(G, x_global, x, opt, crit)
+        np.random.shuffle = patched
+        try:
+            loss_circle = R_utils.circle_contrast(G, x, B, crit)
+        finally:
+            np.random.shuffle = orig_shuffle
+        loss = loss_circle + loss_c
+        optim.zero_grad()
+        loss.backward()
+        if it == 0:
+            h1.remove(); h3.remove()
+            out["train_pooled"] = taps["pooled"].squeeze(-1).permute(0, 2, 1).contiguous().numpy()[::4]   # (M/4,S,256)
+            out["train_x_pre"] = taps["local"].squeeze(-1).max(dim=2).values.numpy()                       # (M,1024)
+            for name, t in zip(("x", "code", "x_nor", "x_global"), (x, code, x_nor, x_global)):
+                out[f"train_{name}"] = t.detach().numpy()
+            out["loss_c"] = np.float64(loss_c.item())
+            out["loss_circle"] = np.float64(loss_circle.item())
+            for k, p in net.named_parameters():
+                if p.grad is None:          # mapping.weight: `code` does not feed the live loss
+                    out[f"gradnone/{k}"] = np.int32(1)
+                    continue
+                g = p.grad.detach().numpy()
+                out[f"gradnorm/{k}"] = np.float64(np.linalg.norm(g.astype(np.float64)))
+                if g.size <= 70000:
+                    out[f"grad/{k}"] = g.copy()
+                else:
+                    out[f"gradhead/{k}"] = g.reshape(-1)[:4096].copy()
+            for k, b in net.named_buffers():
+                out[f"buf1/{k}"] = b.detach().numpy().copy()
+        optim.step()
+        sched.step(0)
+        losses.append(loss.item())
+    out["losses3"] = np.array(losses, dtype=np.float64)
+    for k, b in net.named_buffers():
+        out[f"buf3/{k}"] = b.detach().numpy().copy()
+    for k in ("net3DV_1.0.weight", "net3DV_1.6.weight", "net3DV_3.0.bias", "netR_FC.3.bias", "net3DV_1.4.weight"):
+        out[f"param3/{k}"] = dict(net.named_parameters())[k].detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"c1_{tag}.npz"), **out)
+    print(f"c1_{tag}.npz losses", losses)
+
+
+def main():
+    argparse.ArgumentParser(description=__doc__).parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    make_fps()
+    make_tiny()
+    run_c1(4, False, "d4")
+    run_c1(3, False, "d3")
+    run_c1(4, True, "d4_neg")
+
+
+if __name__ == "__main__":
+    main()

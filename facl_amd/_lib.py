@@ -1,0 +1,77 @@
+"""ctypes binding of libfacl_hip.so (the C ABI declared in include/facl_hip.h).
+
+PyTorch is only plumbing here: tensors provide device memory (``data_ptr()``) and the current
+HIP stream.  ``import torch`` MUST precede the dlopen so that the library binds to the HIP
+runtime PyTorch already loaded (same SONAME libamdhip64.so.7) -- stream handles are only
+meaningful inside one runtime.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded before libfacl_hip.so, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+c_l = ctypes.c_longlong
+
+# name -> argtypes; every function returns int.  Kept in one table so tests can check that the
+# library exports every symbol the header declares.
+SIGNATURES = {
+    "facl_version": [],
+    "facl_fps_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "facl_fps_f64": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "facl_fps_reorder": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
+    "facl_group": [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfacl_hip.so")
+
+
+def load_library():
+    """dlopen the HIP library; raises RuntimeError (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: facl_amd has no CPU/eager fallback. Build it with "
+            "`python -m facl_amd.build` (hipcc --offload-arch=gfx950).")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _LIB = lib
+    return lib
+
+
+_ERR = {-1: "unsupported shape", -2: "NULL pointer", -3: "misaligned pointer", -4: "unsupported configuration"}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("facl_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)

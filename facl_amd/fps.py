@@ -1,0 +1,51 @@
+"""Farthest point sampling on the GPU -- mirrors the reference's NumPy helpers
+``farthest_point_sampling_fast`` / ``fps_sample_data`` (cn3d_data_load.py:287-320,
+cn3D_data_set.py:665-694) with the random start index made explicit."""
+import torch
+
+from . import _lib
+
+
+def farthest_point_sampling_batch(xyz, sample_num, start_idx):
+    """xyz (M,N,>=3) float32|float64 CUDA tensor, start_idx (M,) int -> (M,sample_num) int32.
+    np.argmax tie-break (lowest index), dist^2 = (dx*dx+dy*dy)+dz*dz in xyz's dtype."""
+    _lib.require_cuda(xyz)
+    if xyz.dim() != 3 or xyz.shape[-1] < 3:
+        raise ValueError("xyz must be (M,N,>=3)")
+    xyz = xyz.contiguous()
+    M, N, ld = xyz.shape
+    start = torch.as_tensor(start_idx, device=xyz.device).to(torch.int32).contiguous()
+    if start.numel() != M:
+        raise ValueError("start_idx must have one entry per cloud")
+    out = torch.empty((M, sample_num), dtype=torch.int32, device=xyz.device)
+    lib = _lib.load_library()
+    fn = {torch.float32: lib.facl_fps_f32, torch.float64: lib.facl_fps_f64}.get(xyz.dtype)
+    if fn is None:
+        raise TypeError("xyz must be float32 or float64")
+    _lib.check(fn(_lib.ptr(xyz), M, N, ld, sample_num, _lib.ptr(start), _lib.ptr(out), _lib.stream()), "facl_fps")
+    return out
+
+
+def farthest_point_sampling_fast(pc, sample_num, start_idx=None):
+    """Reference signature (cn3d_data_load.py:301): pc (N,3) -> (sample_num,1) int32.
+    ``start_idx`` replaces the reference's ``np.random.randint(0, pc_num)`` draw; when omitted it
+    is drawn from torch's RNG."""
+    if start_idx is None:
+        start_idx = int(torch.randint(0, pc.shape[0], (1,)).item())
+    return farthest_point_sampling_batch(pc.unsqueeze(0), sample_num, [start_idx]).view(sample_num, 1)
+
+
+def fps_sample_data(points_xyzc, sample_num_level1, start_idx=None):
+    """Reorder every cloud so its FPS picks come first (cn3D_data_set.py:665-672).
+    points (b,N,D) float32 CUDA -> new tensor (the reference permutes in place)."""
+    _lib.require_cuda(points_xyzc)
+    pts = points_xyzc.contiguous().float()
+    b, N, D = pts.shape
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (b,))
+    picks = farthest_point_sampling_batch(pts, sample_num_level1, start_idx)
+    out = torch.empty_like(pts)
+    lib = _lib.load_library()
+    _lib.check(lib.facl_fps_reorder(_lib.ptr(pts), b, N, D, _lib.ptr(picks), sample_num_level1, _lib.ptr(out),
+                                    _lib.stream()), "facl_fps_reorder")
+    return out

@@ -27,7 +27,17 @@ SIGNATURES = {
     "facl_fps_f64": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "facl_fps_reorder": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "facl_group": [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+    "facl_ws_bytes": [],
+    "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],
+    "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],
+    "facl_sa_x_moments": [c_p, c_l, c_i, c_p, c_p, c_p],
+    "facl_bn1_sums_from_moments": [c_p, c_d, c_i, c_p, c_p, c_p, c_p],
+    "facl_sa_l1tab": [c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
 }
+RESTYPE_I64 = {"facl_ws_bytes"}
 
 
 def lib_path():
@@ -48,7 +58,7 @@ def load_library():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_longlong if name in RESTYPE_I64 else ctypes.c_int
     _LIB = lib
     return lib
 

@@ -65,6 +65,46 @@ int facl_fps_reorder(const float* points, int M, int N, int D, const int32_t* pi
 int facl_group(const float* points, int M, int N, int D, int S, int K, float r2,
                int32_t* idx, float* xt, float* yt, void* stream);
 
+/* ---- train-mode BatchNorm plumbing (fp64) -------------------------------------------------
+ * BN semantics: cn3d_model_conbag.py:46,50,54,64,68,72,84 (nn.BatchNorm2d/1d defaults).
+ * `sums` is (C,2) double = per-channel (sum, sum of squares) over `count` positions; under DDP the
+ * host all-reduces `sums` (and adds the counts) between the producing pass and facl_bn_finalize.
+ * `bnc` is (5,C) float: mean, invstd, scale = gamma*invstd, shift = beta - mean*scale, sign(gamma).
+ * running_mean / running_var (may both be NULL) are updated in place with `momentum` and the
+ * unbiased variance, like F.batch_norm(training=True). */
+int64_t facl_ws_bytes(void);   /* size of the scratch buffer `ws` the reducing calls need */
+int facl_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, float* bnc,
+                     void* stream);
+int facl_bn_eval_consts(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* bnc, void* stream);
+
+/* ---- set-abstraction point-MLP forward (net3DV_1, cn3d_model_conbag.py:43-58 / :162-177) ----
+ * x is the grouped input, (P,D) rows = the memory behind the reference's (M,D,S,K) view, P = M*S*K,
+ * K = 64 ("unit" = 64 consecutive rows = one group), D in {3,4}.  Weights are the reference's
+ * tensors as stored in the checkpoint: W1 (64,D), W2 (64,64), W3 (256,64), row-major (Cout,Cin).
+ *   facl_sa_x_moments           x -> mom = [sum_p x (D) | sum_p x x^T (D*D)]  (double)
+ *   facl_bn1_sums_from_moments  mom -> sums of y1 = W1 x + b1 (exact: y1 is affine in x)
+ *   facl_sa_l1tab               fold BN1 into layer 1: l1tab (64,8) = [scale*W1 | scale*b1+shift | 0]
+ *   facl_sa_fwd2                x -> y2 = relu(bn1(y1)) W2^T + b2, stored in "fragment layout"
+ *                               (nunits*4096 floats, see csrc/common.h); sums2 (64,2) or NULL
+ *   facl_sa_fwd3                y2 -> per (group,channel) max_k sgn3*y3 and its argmax k (uint8),
+ *                               y3 = relu(bn2(y2)) W3^T + b3; sums3 (256,2) of sgn3*y3 or NULL
+ *   facl_sa_pool                pooled = relu(|scale3| * ymax + shift3)   (rows,C)
+ */
+int facl_sa_x_moments(const float* x, int64_t P, int D, double* mom, void* ws, void* stream);
+int facl_bn1_sums_from_moments(const double* mom, double count, int D, const float* W1, const float* b1,
+                               double* sums, void* stream);
+int facl_sa_l1tab(const float* W1, const float* b1, int D, const float* scale, const float* shift,
+                  float* l1tab, void* stream);
+int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* l1tab, const float* W2,
+                 const float* b2, float* y2f, double* sums2, void* ws, void* stream);
+int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
+                 const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
+                 double* sums3, void* ws, void* stream);
+int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
+                 float* pooled, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

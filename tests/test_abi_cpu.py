@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "facl_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(facl_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"(?:int|int64_t)\s+(facl_\w+)\s*\(", txt)))
 
 
 def test_library_builds_and_exports_header_symbols():

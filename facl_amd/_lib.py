@@ -36,6 +36,10 @@ SIGNATURES = {
     "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd0": [c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd1": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd_w3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd2": [c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
 }
 RESTYPE_I64 = {"facl_ws_bytes"}
 

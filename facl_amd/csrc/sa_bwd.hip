@@ -1,0 +1,494 @@
+// Set-abstraction point-MLP, backward (autograd of net3DV_1, cn3d_model_conbag.py:43-58).
+//
+// Key identity ("BN-affine folding").  The max-pool sends the gradient to ONE position per
+// (group, channel), but train-mode BN3 makes dL/dy3 dense again:
+//     dy3[p,c] = s3_c*dz3[p,c]  -  (s3_c/P) * (dbeta3_c + yhat3[p,c]*dgamma3_c)
+// The dense part is affine in y3 = a2 W3^T + b3, hence quadratic-form algebra on the 64-wide a2:
+//     da2[p,:] = a2[p,:] G3 + h3 + (sparse rows)        G3 = W3^T diag(g) W3   (64x64)
+//     dW3      = sparse gather  +  closed form in  sum_p a2^T a2  and  sum_p a2
+// so the 256-channel activations are never re-materialised (the stock autograd path stores and
+// re-reads 4.8 GB of them at the headline shape) and layer 3's backward costs 64x64 MFMA work
+// per position instead of 2 x 64x256.
+//
+// Passes (all activations in the fragment layout of common.h, lane = position, register = channel):
+//   facl_sa_bwd0   dpooled -> coef = s3*dz3 (sparse values), sums (dbeta3, dgamma3)
+//   facl_sa_bwd1   y2 -> a2 ; da2 = a2 G3 + h3' + scatter(coef, arg, W3) ; dz2 = da2*[z2>0] (stored);
+//                  sums (dbeta2, dgamma2)
+//   facl_sa_bwd_w3 y2 -> a2 ; Gram sum_p a2^T a2, sum_p a2, sparse part of dW3
+//   facl_sa_bwd2   dz2,y2,x -> dy2 ; da1 = dy2 W2 ; dz1 = da1*[z1>0] ; dW2 += dy2^T a1 ;
+//                  R1 += [x|1]^T dz1   (everything layer 1 needs: dW1, dgamma1, dbeta1 follow in closed form)
+// Roofline: MFMA fp32 for bwd1/bwd2/bwd_w3 (128..320 MFMA 32x32x2 per 64 positions), HBM for bwd0.
+#include "common.h"
+
+int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+
+namespace {
+
+constexpr int SA_GRID = 256;
+constexpr int TP = 68;    // padded row (floats) of a [64 pos][64 ch] LDS tile read with b128 (272 B: 16-B aligned rows)
+constexpr int TQ = 65;    // padded row of a tile accessed with b32 only (conflict-free columns)
+
+// Lanes of ONE wave exchange data through LDS (write in one layout, read in another).  The hardware
+// executes a wave's DS operations in order; this only has to stop the COMPILER from moving LDS
+// accesses across the hand-off (and drain the counter so the data has landed).
+#define WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// ---------------------------------------------------------------------------------------------
+// bwd0: one thread per channel, rows strided over the grid.
+__global__ __launch_bounds__(256) void k_sa_bwd0(const float* __restrict__ dpooled, const float* __restrict__ ymax,
+                                                 int rows, const float* __restrict__ bnc3,
+                                                 float* __restrict__ coef, double* __restrict__ part) {
+    const int c = threadIdx.x;
+    const float mean = bnc3[c], invstd = bnc3[256 + c], scale = bnc3[512 + c], shift = bnc3[768 + c],
+                sgn = bnc3[1024 + c];
+    const float ascale = fabsf(scale);
+    double db = 0, dg = 0;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float ym = ymax[(size_t)r * 256 + c];
+        const float dp = dpooled[(size_t)r * 256 + c];
+        const float z = fmaf(ascale, ym, shift);
+        const float dz = z > 0.f ? dp : 0.f;
+        const float yhat = (sgn * ym - mean) * invstd;
+        coef[(size_t)r * 256 + c] = scale * dz;
+        db += (double)dz;
+        dg += (double)dz * (double)yhat;
+    }
+    part[(size_t)blockIdx.x * 512 + 2 * c] = db;
+    part[(size_t)blockIdx.x * 512 + 2 * c + 1] = dg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bwd1.  LDS: g3f 16 KiB | w3n 64 KiB | tables | 4 x T (64 x 68 floats).
+__global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, int nunits,
+                                                 const float* __restrict__ bnc2, const float* __restrict__ G3,
+                                                 const float* __restrict__ h3, const float* __restrict__ W3,
+                                                 const float* __restrict__ coef, const unsigned char* __restrict__ arg,
+                                                 float* __restrict__ dz2f, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    float4* g3f = lds4;                                   // [rt'][rt][r4][lane]  (1024 float4)
+    float* w3n = reinterpret_cast<float*>(lds4 + 1024);   // W3 natural (256,64)
+    float4* tab = lds4 + 1024 + 4096;                     // mean2, invstd2, scale2, shift2, h3: 5 x 16 float4
+    float* T = reinterpret_cast<float*>(tab + 80) + (threadIdx.x >> 6) * (64 * TP);
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int ln = i & 63, r4 = (i >> 6) & 3, rt = (i >> 8) & 1, rto = i >> 9;
+        g3f[i] = *reinterpret_cast<const float4*>(G3 + (32 * rto + (ln & 31)) * 64 + 32 * rt + 8 * r4 + 4 * (ln >> 5));
+    }
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        reinterpret_cast<float4*>(w3n)[i] = reinterpret_cast<const float4*>(W3)[i];
+    if (threadIdx.x < 64) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2)[threadIdx.x];   // 4 x 64 floats
+    if (threadIdx.x < 16) tab[64 + threadIdx.x] = reinterpret_cast<const float4*>(h3)[threadIdx.x];
+    __syncthreads();
+    const float4* mean2 = tab; const float4* inv2 = tab + 16; const float4* sc2 = tab + 32; const float4* sh2 = tab + 48;
+    const float4* h3s = tab + 64;
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float pb[2][16], pg[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pb[a][r] = 0.f; pg[a][r] = 0.f; }
+
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        asm volatile("" ::: "memory");
+        // ---- sparse rows: T[arg][j] += coef * W3[c][j]
+        for (int i = lane; i < 64 * TP / 4; i += 64) reinterpret_cast<float4*>(T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        WAVE_LDS_FENCE();
+        const float4 cf4 = *reinterpret_cast<const float4*>(coef + (size_t)u * 256 + 4 * lane);
+        const uchar4 ar4 = *reinterpret_cast<const uchar4*>(arg + (size_t)u * 256 + 4 * lane);
+        const float cfv[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
+        const int arv[4] = {ar4.x, ar4.y, ar4.z, ar4.w};
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfv[e]), i));
+                if (cf != 0.f) {                                   // wave-uniform
+                    const int ps = __builtin_amdgcn_readlane(arv[e], i);
+                    const float w = w3n[(4 * i + e) * 64 + lane];
+                    atomicAdd(&T[ps * TP + lane], cf * w);         // ds_add_f32, in-order within the wave
+                }
+            }
+        }
+        WAVE_LDS_FENCE();      // other lanes read T below
+        // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j]
+        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+        float yv[2][2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 y = *reinterpret_cast<const float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4);
+                    yv[ct][rt][4 * r4] = y.x; yv[ct][rt][4 * r4 + 1] = y.y; yv[ct][rt][4 * r4 + 2] = y.z; yv[ct][rt][4 * r4 + 3] = y.w;
+                }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 hh = h3s[8 * ro + 2 * r4 + h];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[ro][ct][4 * r4] = hh.x; acc[ro][ct][4 * r4 + 1] = hh.y; acc[ro][ct][4 * r4 + 2] = hh.z; acc[ro][ct][4 * r4 + 3] = hh.w;
+                }
+            }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 sc = sc2[8 * rt + 2 * r4 + h], sh = sh2[8 * rt + 2 * r4 + h];
+                const float4 f0 = g3f[((0 * 2 + rt) * 4 + r4) * 64 + lane], f1 = g3f[((1 * 2 + rt) * 4 + r4) * 64 + lane];
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                const float fa0[4] = {f0.x, f0.y, f0.z, f0.w}, fa1[4] = {f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a20 = fmaxf(fmaf(scv[e], yv[0][rt][4 * r4 + e], shv[e]), 0.f);
+                    const float a21 = fmaxf(fmaf(scv[e], yv[1][rt][4 * r4 + e], shv[e]), 0.f);
+                    acc[0][0] = MFMA32(fa0[e], a20, acc[0][0]);
+                    acc[0][1] = MFMA32(fa0[e], a21, acc[0][1]);
+                    acc[1][0] = MFMA32(fa1[e], a20, acc[1][0]);
+                    acc[1][1] = MFMA32(fa1[e], a21, acc[1][1]);
+                }
+            }
+        // ---- combine, mask with z2 > 0, store dz2, accumulate dbeta2 / dgamma2
+        float* otile = dz2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 t = *reinterpret_cast<const float4*>(&T[(32 * ct + q) * TP + 32 * ro + 8 * r4 + 4 * h]);
+                    const float4 sc = sc2[8 * ro + 2 * r4 + h], sh = sh2[8 * ro + 2 * r4 + h];
+                    const float4 mu = mean2[8 * ro + 2 * r4 + h], iv = inv2[8 * ro + 2 * r4 + h];
+                    const float tv[4] = {t.x, t.y, t.z, t.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, ivv[4] = {iv.x, iv.y, iv.z, iv.w};
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = yv[ct][ro][4 * r4 + e];
+                        const bool on = fmaf(scv[e], y, shv[e]) > 0.f;
+                        const float d = on ? acc[ro][ct][4 * r4 + e] + tv[e] : 0.f;
+                        o[e] = d;
+                        pb[ro][4 * r4 + e] += d;
+                        pg[ro][4 * r4 + e] = fmaf(d, (y - muv[e]) * ivv[e], pg[ro][4 * r4 + e]);
+                    }
+                    *reinterpret_cast<float4*>(otile + (((ct * 2 + ro) * 4 + r4) * 64 + lane) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+    }
+#pragma unroll
+    for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double s = pb[ro][r], g = pg[ro][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); g += __shfl_xor(g, o, 64); }
+            if (q == 0) {
+                const int c = 32 * ro + rowmap(r, h);
+                part[(size_t)wave_g * 128 + 2 * c] = s;
+                part[(size_t)wave_g * 128 + 2 * c + 1] = g;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bwd_w3: one workgroup per unit at a time.  Output row per workgroup:
+//   [ sparse dW3 (256 x 64) | Gram sum a2^T a2 (64 x 64) | sum a2 (64) ]  = 20544 doubles
+constexpr int W3_V = 256 * 64 + 64 * 64 + 64;
+
+__global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f, int nunits,
+                                                   const float* __restrict__ bnc2, const float* __restrict__ coef,
+                                                   const unsigned char* __restrict__ arg, double* __restrict__ part) {
+    __shared__ float T[64 * TQ];
+    __shared__ float4 tab[32];       // scale2, shift2
+    if (threadIdx.x < 32) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2 + 128)[threadIdx.x];
+    __syncthreads();
+    const float* sc2 = reinterpret_cast<const float*>(tab);
+    const float* sh2 = sc2 + 64;
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31, wave = threadIdx.x >> 6;
+    const int c = threadIdx.x;                         // sparse part: this thread's output channel
+    float accs[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) accs[k] = 0.f;
+    f32x16 gram;                                       // Gram tile (rt = wave>>1, ct = wave&1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gram[r] = 0.f;
+    const int grt = wave >> 1, gct = wave & 1;
+    float s2 = 0.f;                                    // waves 0,1: sum_p a2[p][32*wave + q] over this lane's positions
+
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+        __syncthreads();                               // previous unit's readers are done with T
+        // each wave converts one (ct, rt) quarter of the tile: element (p = 32ct+q, c = 32rt + 8r4 + 4h + e)
+        {
+            const int ct = wave >> 1, rt = wave & 1;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 y = *reinterpret_cast<const float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4);
+                const int c0 = 32 * rt + 8 * r4 + 4 * h;
+                float* dst = &T[(32 * ct + q) * TQ + c0];
+                dst[0] = fmaxf(fmaf(sc2[c0], y.x, sh2[c0]), 0.f);
+                dst[1] = fmaxf(fmaf(sc2[c0 + 1], y.y, sh2[c0 + 1]), 0.f);
+                dst[2] = fmaxf(fmaf(sc2[c0 + 2], y.z, sh2[c0 + 2]), 0.f);
+                dst[3] = fmaxf(fmaf(sc2[c0 + 3], y.w, sh2[c0 + 3]), 0.f);
+            }
+        }
+        const float cf = coef[(size_t)u * 256 + c];
+        const int ps = arg[(size_t)u * 256 + c];
+        __syncthreads();
+        // Gram tile: G[i][j] += sum_p a2[p][32grt+i] a2[p][32gct+j];  A/B lane (h,q): a2[p = 32h+s][32t+q]
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float av = T[(32 * h + s) * TQ + 32 * grt + q];
+            const float bv = T[(32 * h + s) * TQ + 32 * gct + q];
+            gram = MFMA32(av, bv, gram);
+            if (wave < 2) s2 += bv;                    // waves 0,1 have gct = wave: column 32*wave+q
+        }
+        // sparse part: dW3[c][:] += coef * a2[arg][:]
+        if (cf != 0.f) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) accs[k] = fmaf(cf, T[ps * TQ + k], accs[k]);
+        }
+    }
+    double* row = part + (size_t)blockIdx.x * W3_V;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) row[(size_t)c * 64 + k] = (double)accs[k];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        row[256 * 64 + (32 * grt + rowmap(r, h)) * 64 + 32 * gct + q] = (double)gram[r];
+    if (wave < 2) {
+        const float tot = s2 + __shfl_xor(s2, 32, 64);
+        if (h == 0) row[256 * 64 + 64 * 64 + 32 * wave + q] = (double)tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bwd2.  Output row per wave: [ dW2 (64 x 64, [c2][c1]) | R1 (8 x 64, rows: x_0..x_{D-1}, 1, 0..) ] = 4608 doubles
+constexpr int B2_V = 64 * 64 + 8 * 64;
+
+template <int D>
+__global__ __launch_bounds__(256) void k_sa_bwd2(const float* __restrict__ dz2f, const float* __restrict__ y2f,
+                                                 const float* __restrict__ x, int nunits,
+                                                 const float* __restrict__ bw2 /* (4,64): scale2, A, B, mean2 */,
+                                                 const float* __restrict__ W2, const float* __restrict__ l1tab_g,
+                                                 double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    float4* w2t = lds4;                                    // A frags of W2^T: [rt'][rt][r4][lane] (1024 float4)
+    float4* l1tab = lds4 + 1024;                           // 128 float4
+    float4* tab = l1tab + 128;                             // 4 x 16 float4
+    float* Tbase = reinterpret_cast<float*>(tab + 64);
+    float* T = Tbase + (threadIdx.x >> 6) * (2 * 64 * TQ + 64 * 8);   // tile A: dy2, later dz1
+    float* T2 = T + 64 * TQ;                               // tile B: a1
+    float* xs = T2 + 64 * TQ;                              // [64 pos][8]: x_0..x_{D-1}, 1, 0...
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int ln = i & 63, r4 = (i >> 6) & 3, rt = (i >> 8) & 1, rto = i >> 9;
+        const int c1 = 32 * rto + (ln & 31), c2 = 32 * rt + 8 * r4 + 4 * (ln >> 5);
+        w2t[i] = make_float4(W2[(c2 + 0) * 64 + c1], W2[(c2 + 1) * 64 + c1], W2[(c2 + 2) * 64 + c1], W2[(c2 + 3) * 64 + c1]);
+    }
+    if (threadIdx.x < 128) l1tab[threadIdx.x] = reinterpret_cast<const float4*>(l1tab_g)[threadIdx.x];
+    if (threadIdx.x < 64) tab[threadIdx.x] = reinterpret_cast<const float4*>(bw2)[threadIdx.x];
+    __syncthreads();
+    const float4* sc2 = tab; const float4* cA = tab + 16; const float4* cB = tab + 32; const float4* mean2 = tab + 48;
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    f32x16 dw2[2][2], r1[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dw2[0][0][r] = dw2[0][1][r] = dw2[1][0][r] = dw2[1][1][r] = 0.f; r1[0][r] = r1[1][r] = 0.f; }
+
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        asm volatile("" ::: "memory");
+        const float* zt = dz2f + (size_t)u * FACL_UNIT_ELEMS;
+        const float* yt = y2f + (size_t)u * FACL_UNIT_ELEMS;
+        // x tile of the unit -> LDS (position-major, padded to 8) and this lane's two positions in registers
+        float xv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const size_t p = (size_t)u * 64 + 32 * ct + q;
+            if (D == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(x + p * 4);
+                xv[ct][0] = t.x; xv[ct][1] = t.y; xv[ct][2] = t.z; xv[ct][3] = t.w;
+            } else {
+                xv[ct][0] = x[p * 3]; xv[ct][1] = x[p * 3 + 1]; xv[ct][2] = x[p * 3 + 2]; xv[ct][3] = 0.f;
+            }
+            if (h == 0) {
+                float4 lo = make_float4(xv[ct][0], xv[ct][1], xv[ct][2], D == 4 ? xv[ct][3] : 1.f);
+                float4 hi = make_float4(D == 4 ? 1.f : 0.f, 0.f, 0.f, 0.f);
+                reinterpret_cast<float4*>(xs)[(32 * ct + q) * 2] = lo;
+                reinterpret_cast<float4*>(xs)[(32 * ct + q) * 2 + 1] = hi;
+            }
+        }
+        // dy2 (lane = position, register = c2) and its copy in T for the transposed read-back
+        float dy2[2][2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const size_t o = (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4;
+                    const float4 z = *reinterpret_cast<const float4*>(zt + o);
+                    const float4 y = *reinterpret_cast<const float4*>(yt + o);
+                    const int ti = 8 * rt + 2 * r4 + h;
+                    const float4 s = sc2[ti], a = cA[ti], b = cB[ti], m = mean2[ti];
+                    const float d0 = fmaf(s.x, z.x, fmaf(b.x, y.x - m.x, a.x));
+                    const float d1 = fmaf(s.y, z.y, fmaf(b.y, y.y - m.y, a.y));
+                    const float d2 = fmaf(s.z, z.z, fmaf(b.z, y.z - m.z, a.z));
+                    const float d3 = fmaf(s.w, z.w, fmaf(b.w, y.w - m.w, a.w));
+                    dy2[ct][rt][4 * r4] = d0; dy2[ct][rt][4 * r4 + 1] = d1; dy2[ct][rt][4 * r4 + 2] = d2; dy2[ct][rt][4 * r4 + 3] = d3;
+                    float* dst = &T[(32 * ct + q) * TQ + 32 * rt + 8 * r4 + 4 * h];
+                    dst[0] = d0; dst[1] = d1; dst[2] = d2; dst[3] = d3;
+                }
+        WAVE_LDS_FENCE();
+        // da1^T[c1][p] = sum_c2 W2[c2][c1] dy2[p][c2]
+        f32x16 da1[2][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) da1[0][0][r] = da1[0][1][r] = da1[1][0][r] = da1[1][1][r] = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 f0 = w2t[((0 * 2 + rt) * 4 + r4) * 64 + lane], f1 = w2t[((1 * 2 + rt) * 4 + r4) * 64 + lane];
+                const float fa0[4] = {f0.x, f0.y, f0.z, f0.w}, fa1[4] = {f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    da1[0][0] = MFMA32(fa0[e], dy2[0][rt][4 * r4 + e], da1[0][0]);
+                    da1[0][1] = MFMA32(fa0[e], dy2[1][rt][4 * r4 + e], da1[0][1]);
+                    da1[1][0] = MFMA32(fa1[e], dy2[0][rt][4 * r4 + e], da1[1][0]);
+                    da1[1][1] = MFMA32(fa1[e], dy2[1][rt][4 * r4 + e], da1[1][1]);
+                }
+            }
+        // a1 (same lane = position layout as da1), dz1 = da1 * [a1 > 0]; a1 -> T
+        float dz1[2][2][16];
+#pragma unroll
+        for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c1 = 32 * ro + rowmap(r, h);
+                const float4 w = l1tab[c1 * 2];
+                const float b = l1tab[c1 * 2 + 1].x;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    float v = fmaf(w.x, xv[ct][0], b);
+                    v = fmaf(w.y, xv[ct][1], v);
+                    v = fmaf(w.z, xv[ct][2], v);
+                    if (D == 4) v = fmaf(w.w, xv[ct][3], v);
+                    const float a1 = fmaxf(v, 0.f);
+                    dz1[ro][ct][r] = v > 0.f ? da1[ro][ct][r] : 0.f;
+                    T2[(32 * ct + q) * TQ + c1] = a1;
+                }
+            }
+        WAVE_LDS_FENCE();
+        // dW2[c2][c1] += sum_p dy2[p][c2] a1[p][c1]; operands read back in (lane = channel, k = position 32h+s)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float dy0 = T[(32 * h + s) * TQ + q], dy1 = T[(32 * h + s) * TQ + 32 + q];
+            const float aa0 = T2[(32 * h + s) * TQ + q], aa1 = T2[(32 * h + s) * TQ + 32 + q];
+            dw2[0][0] = MFMA32(dy0, aa0, dw2[0][0]);
+            dw2[0][1] = MFMA32(dy0, aa1, dw2[0][1]);
+            dw2[1][0] = MFMA32(dy1, aa0, dw2[1][0]);
+            dw2[1][1] = MFMA32(dy1, aa1, dw2[1][1]);
+        }
+        WAVE_LDS_FENCE();
+        // dz1 -> T -> (lane = c1, register = position) ; R1[d][c1] += sum_p xe[p][d] dz1[p][c1]
+#pragma unroll
+        for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) T[(32 * ct + q) * TQ + 32 * ro + rowmap(r, h)] = dz1[ro][ct][r];
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float xa = q < 8 ? xs[(32 * h + s) * 8 + q] : 0.f;
+            const float z0 = T[(32 * h + s) * TQ + q], z1 = T[(32 * h + s) * TQ + 32 + q];
+            r1[0] = MFMA32(xa, z0, r1[0]);
+            r1[1] = MFMA32(xa, z1, r1[1]);
+        }
+        WAVE_LDS_FENCE();      // next unit overwrites T / xs
+    }
+    double* row = part + (size_t)wave_g * B2_V;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) row[(32 * a + rowmap(r, h)) * 64 + 32 * b + q] = (double)dw2[a][b][r];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = rowmap(r, h);
+            if (d < 8) row[64 * 64 + d * 64 + 32 * b + q] = (double)r1[b][r];
+        }
+}
+
+}  // namespace
+
+extern "C" int facl_sa_bwd0(const float* dpooled, const float* ymax, int64_t rows, const float* bnc3, float* coef,
+                            double* sums, void* ws, void* stream) {
+    if (!dpooled || !ymax || !bnc3 || !coef || !sums || !ws) return FACL_E_NULL;
+    if (rows < 1 || rows > 0x7fffffff) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(rows < 1024 ? rows : 1024);
+    hipLaunchKernelGGL(k_sa_bwd0, dim3(grid), dim3(256), 0, st, dpooled, ymax, (int)rows, bnc3, coef, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, grid, 512, sums, st);
+}
+
+extern "C" int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2, const float* G3, const float* h3,
+                            const float* W3, const float* coef, const uint8_t* arg, float* dz2f, double* sums,
+                            void* ws, void* stream) {
+    if (!y2f || !bnc2 || !G3 || !h3 || !W3 || !coef || !arg || !dz2f || !sums || !ws) return FACL_E_NULL;
+    if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
+    const size_t lds = (1024 + 4096 + 80) * sizeof(float4) + 4 * 64 * TP * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_sa_bwd1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_sa_bwd1, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, G3, h3, W3, coef, arg, dz2f,
+                       (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, grid * 4, 128, sums, st);
+}
+
+extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc2, const float* coef,
+                              const uint8_t* arg, double* out /* 20544 */, void* ws, void* stream) {
+    if (!y2f || !bnc2 || !coef || !arg || !out || !ws) return FACL_E_NULL;
+    if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(nunits < 512 ? nunits : 512);
+    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), 0, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, grid, W3_V, out, st);
+}
+
+extern "C" int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nunits, int D,
+                            const float* bw2, const float* W2, const float* l1tab, double* out /* 4608 */, void* ws,
+                            void* stream) {
+    if (!dz2f || !y2f || !x || !bw2 || !W2 || !l1tab || !out || !ws) return FACL_E_NULL;
+    if ((D != 3 && D != 4) || nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
+    const size_t lds = (1024 + 128 + 64) * sizeof(float4) + 4 * (2 * 64 * TQ + 64 * 8) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_sa_bwd2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_sa_bwd2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+        attr_done = true;
+    }
+    if (D == 4) hipLaunchKernelGGL((k_sa_bwd2<4>), dim3(grid), dim3(256), lds, st, dz2f, y2f, x, (int)nunits, bw2, W2, l1tab, (double*)ws);
+    else hipLaunchKernelGGL((k_sa_bwd2<3>), dim3(grid), dim3(256), lds, st, dz2f, y2f, x, (int)nunits, bw2, W2, l1tab, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, grid * 4, B2_V, out, st);
+}

@@ -105,6 +105,30 @@ int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const fl
 int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
                  float* pooled, void* stream);
 
+/* ---- set-abstraction point-MLP backward (autograd of net3DV_1) ---------------------------
+ * See csrc/sa_bwd.hip for the algebra ("BN-affine folding": the dense part of BN3's backward is
+ * affine in y3, so layer 3's backward is 64x64 work per position and y3 is never re-materialised).
+ *   facl_sa_bwd0    dpooled (rows,256), ymax, bnc3 (5,256) -> coef = scale3*dz3 (rows,256),
+ *                   sums (256,2) = (dbeta3, dgamma3)
+ *   facl_sa_bwd1    y2f, bnc2 (5,64), G3 (64,64), h3 (64), W3, coef, arg -> dz2f (fragment layout),
+ *                   sums (64,2) = (dbeta2, dgamma2)
+ *   facl_sa_bwd_w3  y2f, bnc2, coef, arg -> out (20544 doubles) =
+ *                   [ sum_g coef*a2[arg] (256,64) | sum_p a2^T a2 (64,64) | sum_p a2 (64) ]
+ *   facl_sa_bwd2    dz2f, y2f, x, bw2 (4,64) = [scale2 | A | B | mean2] with dy2 = scale2*dz2 + A + B*(y2-mean2),
+ *                   W2, l1tab -> out (4608 doubles) = [ dW2 (64,64) | R1 (8,64) ], R1 rows = sum_p x_d*dz1
+ *                   (d < D), then sum_p dz1, then zeros.
+ */
+int facl_sa_bwd0(const float* dpooled, const float* ymax, int64_t rows, const float* bnc3, float* coef,
+                 double* sums, void* ws, void* stream);
+int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2, const float* G3, const float* h3,
+                 const float* W3, const float* coef, const uint8_t* arg, float* dz2f, double* sums,
+                 void* ws, void* stream);
+int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc2, const float* coef,
+                   const uint8_t* arg, double* out, void* ws, void* stream);
+int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nunits, int D,
+                 const float* bw2, const float* W2, const float* l1tab, double* out, void* ws,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,54 @@ def test_sa_forward_c1_golden():
     pooled, _ = sa_mlp.sa_mlp_forward(xt.permute(0, 2, 3, 1).reshape(-1, 4), p, True)
     mine = pooled.view(32, 64, 256).cpu().numpy()[::4]
     assert max_rel_rows(mine, g["train_pooled"]) < 1e-4
+
+
+@pytest.mark.parametrize("D,neg", [(4, False), (3, False), (4, True)])
+def test_sa_backward_vs_oracle_fp64(D, neg):
+    """Parameter gradients of net3DV_1 for a random upstream gradient vs fp64 autograd of the oracle."""
+    from facl_amd import sa_mlp, utils_my
+    from oracle import encoder as E
+    from oracle.weights import formula_state_dict
+    torch.manual_seed(10 + D)
+    M, N, S, K = 6, 512, 64, 64
+    pts = (torch.rand(M, N, D) - 0.5)
+    xt, yt = utils_my.knn_radius_group(pts.to(DEV), S, K, 0.06)
+    sd = formula_state_dict(D, neg_gamma=neg)
+    p = _params(sd, DEV)
+    x_rows = xt.permute(0, 2, 3, 1).reshape(-1, D)
+    names = sa_mlp._PARAM_ORDER
+    params = [p[k].clone().requires_grad_(True) for k in names]
+    state = dict(training=True, buffers={k: p[k] for k in ("rm1", "rv1", "rm2", "rv2", "rm3", "rv3")})
+    pooled = sa_mlp.SAMLPFunction.apply(x_rows, state, *params)
+    up = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    up = up * (torch.rand(up.shape, generator=torch.Generator().manual_seed(2)).to(DEV) > 0.3)   # some exact zeros
+    (pooled * up).sum().backward()
+
+    def ref(dtype):
+        sdr = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
+               for k, v in sd.items()}
+        keys = [k for k in sdr if k.startswith("net3DV_1") and "running" not in k and "num_batches" not in k]
+        for k in keys:
+            sdr[k].requires_grad_(True)
+        h = xt.cpu().to(dtype)
+        for li in (0, 3, 6):
+            h = E._conv_bn_relu(sdr, "net3DV_1", li, h, True)
+        pl = F.max_pool2d(h, (1, K), stride=1).squeeze(-1).permute(0, 2, 1).reshape(-1, 256)
+        (pl * up.cpu().to(dtype)).sum().backward()
+        return {k: sdr[k].grad for k in keys}
+
+    g64, g32 = ref(torch.float64), ref(torch.float32)
+    keymap = {"W1": "net3DV_1.0.weight", "b1": "net3DV_1.0.bias", "g1": "net3DV_1.1.weight", "be1": "net3DV_1.1.bias",
+              "W2": "net3DV_1.3.weight", "b2": "net3DV_1.3.bias", "g2": "net3DV_1.4.weight", "be2": "net3DV_1.4.bias",
+              "W3": "net3DV_1.6.weight", "b3": "net3DV_1.6.bias", "g3": "net3DV_1.7.weight", "be3": "net3DV_1.7.bias"}
+    for k, prm in zip(names, params):
+        r64 = g64[keymap[k]].numpy()
+        mine = prm.grad.cpu().numpy().reshape(r64.shape)
+        if k in ("b1", "b2", "b3"):                    # mathematically zero (bias before a train-mode BN)
+            assert np.abs(mine).max() == 0.0
+            continue
+        e_mine = rel_err(mine, r64)
+        e_t32 = rel_err(g32[keymap[k]].numpy(), r64)
+        print(f"{k}: mine-vs-fp64 {e_mine:.2e}  torch-fp32-vs-fp64 {e_t32:.2e}")
+        assert e_mine < 1e-4, k
+        assert e_mine < 3 * e_t32 + 1e-5, k

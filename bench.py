@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- contrastive-step clips/sec on synthetic clouds (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of the reference loop body (cn3d_train_motion_GL.py:224-335) on a
+batch already resident in HBM: view-major reshape -> kNN/radius grouping -> encoder forward -> global + circle
+loss -> backward -> Adam.  Workload at N=1 = BASELINE.json configs[1]: motion stream, B=32, T=24 views,
+N=2048 points.  Weak scaling: every rank processes its own B=32 clips; the embeddings all-gather, SyncBN
+all-reduces and the gradient all-reduce are the exchange steps (facl_amd/dist.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--B", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--T", type=int, default=24, help="views per clip (reference: gost / num_crop)")
+    ap.add_argument("--N", type=int, default=2048)
+    ap.add_argument("--D", type=int, default=3, help="input channels (north_star: 3-ch; checkpoints: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_opt(a):
+    from types import SimpleNamespace
+    return SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                           sample_num_level2=64, INPUT_FEATURE_NUM=a.D, Num_Class=512, batchSize=a.B,
+                           pooling="concatenation", SAMPLE_NUM=a.N)
+
+
+def dominant_kernel_roofline(a, dev):
+    """Live timing of the dominant kernel (k_sa_fwd3: y2 -> a2 -> 64->256 MFMA layer + BN stats + max/argmax)
+    with HIP events on the stream it is launched on.  Algorithmic FLOPs per launch = 2*64*256 per position x
+    M*S*K positions (the 64->256 term of the SA-MLP)."""
+    from facl_amd import _lib
+    from facl_amd.sa_mlp import _Workspace
+    lib = _lib.load_library()
+    nunits = a.B * a.T * 64
+    y2f = torch.randn(nunits * 4096, device=dev)
+    sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    W3, b3 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+    sgn = torch.ones(256, device=dev)
+    ymax = torch.empty(nunits, 256, device=dev)
+    arg = torch.empty(nunits, 256, dtype=torch.uint8, device=dev)
+    sums = torch.empty(256, 2, dtype=torch.float64, device=dev)
+    ws = _Workspace.get(dev)
+    st = torch.cuda.current_stream()
+
+    def launch():
+        _lib.check(lib.facl_sa_fwd3(_lib.ptr(y2f), nunits, _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(W3), _lib.ptr(b3),
+                                    _lib.ptr(sgn), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums), _lib.ptr(ws),
+                                    st.cuda_stream), "facl_sa_fwd3")
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 10
+    e0.record(st)
+    for _ in range(iters):
+        launch()
+    e1.record(st)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters        # includes the 2-us partial-sum reduce that follows each launch
+    flops = 2.0 * 64 * 256 * nunits * 64
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "k_sa_fwd3", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+            "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(a):
+    """The oracle's training step (a port of the reference's op sequence onto torch-CPU) timed on the host
+    cores, on a bounded sample: `cpu_clips` clips of the same (T, N, D) shape."""
+    from oracle import step as OS
+    from oracle import encoder as E
+    from oracle.weights import formula_state_dict
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    Bc, G = a.cpu_clips, a.T
+    sd = E.clone_state(formula_state_dict(a.D))
+    opt = OS.AdamState(sd)
+    g = torch.Generator().manual_seed(0)
+    order = np.arange(G)
+    times = []
+    for it in range(3):
+        pts = OS.view_major(torch.rand(Bc, G, a.N, a.D, generator=g) - 0.5)
+        t0 = time.time()
+        OS.train_step(sd, opt, pts, Bc, G, 64, 64, 0.16 if a.N != 512 else 0.06, order)
+        times.append(time.time() - t0)
+    t = min(times[1:])
+    return {"value": round(Bc / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"B={Bc} clips x T={G} views x N={a.N} pts, D={a.D}: 1 warm-up + 2 timed steps "
+                      f"(best {t:.2f} s/step) of oracle.step.train_step"}
+
+
+def main():
+    a = parse()
+    from facl_amd import dist as fdist
+    rank, world = fdist.init_from_env()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.train_common import ContrastiveStep, synthetic_batch
+
+    torch.manual_seed(1)                       # opt.manualSeed = 1 (cn3d_train_motion_GL.py:142-144)
+    np.random.seed(1)
+    opt = make_opt(a)
+    net = PointNet_Plus(opt, gost=a.T).to(dev).train()
+    net.bn_reduce_fn = fdist.make_bn_reduce_fn()
+    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
+    step = ContrastiveStep(net, optim, opt, a.T)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]   # resident in HBM
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(batches[i % 2], epoch=0)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss, _, _ = step(batches[i % 2], epoch=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        clips = a.B * world * a.steps / dt
+        out = {"metric": "contrastive-step clips/sec (B=32,T=24,N=2048)", "value": round(clips, 2), "unit": "clips/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"motion stream, B={a.B}/GPU T={a.T} N={a.N} D={a.D}, S=64 K=64, full "
+                                      f"cn3d_model_conbag encoder, global+circle loss, backward, Adam",
+                          "global_batch": a.B * world, "parallelism": f"dp{world}"},
+               "final_loss": final_loss}
+        out["roofline"] = dominant_kernel_roofline(a, dev)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""Data-parallel plumbing: one process per GPU over RCCL (torch.distributed backend "nccl" on ROCm).
+
+The reference is single-process (nn.DataParallel pinned to one device, cn3d_train_motion_GL.py:33,176);
+its only collective helper, ``concat_all_gather`` (cn3d_model_conbag.py:559-570), is unreachable.  Here
+clips are sharded across ranks and three exchanges make the R-rank step equal the 1-rank step at the
+global batch:
+  1. embeddings all-gather (autograd-aware) before the losses  -> cross-GPU negatives,
+  2. SyncBN: all-reduce of the (sum, sumsq) / (dbeta, dgamma) fp64 buffers between kernel passes,
+  3. gradient all-reduce (one flat 9.4 MB bucket), averaged.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return 0, world if dist.is_initialized() else 1
+    rank = int(os.environ["RANK"])
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def make_bn_reduce_fn(group=None):
+    """In-place SUM all-reduce of an fp64 statistics buffer (SyncBN hook of the BN passes)."""
+    if not is_distributed():
+        return None
+
+    def reduce_fn(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    return reduce_fn
+
+
+class _AllGatherViewMajor(torch.autograd.Function):
+    """(G*B_l, C) view-major local rows -> (G*R*B_l, C) view-major global rows (row = g*(R*B_l) + r*B_l + b).
+
+    Forward semantics follow ``concat_all_gather`` (gather list -> cat), plus the re-layout that the
+    view-major row order needs (SURVEY hard part 5).  Backward = sum over ranks of the gathered gradient,
+    sliced back to the local rows (the single-process loss back-propagates through the negatives)."""
+
+    @staticmethod
+    def forward(ctx, x, G, group):
+        R = dist.get_world_size(group)
+        r = dist.get_rank(group)
+        xs = [torch.empty_like(x) for _ in range(R)]
+        dist.all_gather(xs, x.contiguous(), group=group)
+        Bl, C = x.shape[0] // G, x.shape[1]
+        full = torch.stack([t.view(G, Bl, C) for t in xs], dim=1)           # (G,R,Bl,C)
+        ctx.meta = (G, R, r, Bl, C, group)
+        return full.reshape(G * R * Bl, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        G, R, r, Bl, C, group = ctx.meta
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        return g.view(G, R, Bl, C)[:, r].reshape(G * Bl, C), None, None
+
+
+def all_gather_view_major(x, G, group=None):
+    if not is_distributed():
+        return x
+    return _AllGatherViewMajor.apply(x, G, group)
+
+
+def allreduce_gradients(params, group=None):
+    """Average the gradients across ranks through ONE flat fp32 bucket (2.36 M params = 9.4 MB:
+    latency-bound on xGMI, so a single collective beats per-tensor calls)."""
+    if not is_distributed():
+        return
+    ps = [p for p in params if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    o = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n

@@ -1,0 +1,157 @@
+"""Shared body of the two training entries (the reference ships two scripts that differ in three
+lines: default ``branch_choose``, data root and checkpoint file name -- cn3d_train_apperance_GL.py:135,161,341)."""
+import argparse
+import logging
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import cn3d_model_conbag as MODELL
+from . import dist as fdist
+from .utils_my import circle_contrast, global_contrast, group_points_3DV, knn_radius_group
+
+
+def build_parser(default_branch):
+    """Flags of cn3d_train_motion_GL.py:77-135 (names, types and defaults unchanged) plus the additions
+    marked NEW: synthetic data (the NTU files are not redistributable), real grouping parameters
+    (the reference overrides knn_K / ball_radius with literals inside the grouper, utils_my.py:260-261)."""
+    p = argparse.ArgumentParser(description="Training")
+    p.add_argument('--batchSize', type=int, default=64, help='input batch size')
+    p.add_argument('--nepoch', type=int, default=100, help='number of epochs to train for')
+    p.add_argument('--INPUT_FEATURE_NUM', type=int, default=4, help='number of input point features')
+    p.add_argument('--temperal_num', type=int, default=3, help='number of input point features')
+    p.add_argument('--pooling', type=str, default='concatenation')
+    p.add_argument('--dataset', type=str, default='ntu60')
+    p.add_argument('--weight_decay', type=float, default=0.0008, help='weight decay (SGD only)')
+    p.add_argument('--learning_rate', type=float, default=0.0003, help='learning rate at t=0')
+    p.add_argument('--momentum', type=float, default=0.9, help='momentum (SGD only)')
+    p.add_argument('--workers', type=int, default=0, help='number of data loading workers')
+    p.add_argument('--root_path', type=str, default='../ntu/ntu60_new2/raw/', help='preprocess folder')
+    p.add_argument('--depth_path', type=str, default='', help='raw_depth_png')
+    p.add_argument('--save_root_dir', type=str, default='../ntu/ntu60_new2/model/', help='output folder')
+    p.add_argument('--model', type=str, default='', help='model name for training resume')
+    p.add_argument('--optimizer', type=str, default='', help='optimizer name for training resume')
+    p.add_argument('--ngpu', type=int, default=1, help='# GPUs')
+    p.add_argument('--main_gpu', type=int, default=0, help='main GPU id')
+    p.add_argument('--emb_dims', type=int, default=1024)
+    p.add_argument('--k', type=int, default=20)
+    p.add_argument('--dropout', type=float, default=0.05)
+    p.add_argument('--learning_rate_decay', type=float, default=1e-7)
+    p.add_argument('--size', type=str, default='full')
+    p.add_argument('--SAMPLE_NUM', type=int, default=512, help='number of sample points')
+    p.add_argument('--Num_Class', type=int, default=512, help='number of outputs')
+    p.add_argument('--knn_K', type=int, default=64, help='K for knn search')
+    p.add_argument('--sample_num_level1', type=int, default=64, help='number of first layer groups')
+    p.add_argument('--sample_num_level2', type=int, default=64, help='number of second layer groups')
+    p.add_argument('--ball_radius', type=float, default=0.16, help='square of radius for ball query in level 1')
+    p.add_argument('--ball_radius2', type=float, default=0.25, help='square of radius for ball query in level 2')
+    p.add_argument('--ex_feature', type=int, default=7)
+    p.add_argument('--save_feature_dir', type=str, default='../ntu/ntu60_new2/features/')
+    p.add_argument('--save_label_dir', type=str, default='../ntu/ntu60_new2/labels/')
+    p.add_argument('--branch_choose', type=str, default=default_branch)
+    # NEW
+    p.add_argument('--synthetic', type=int, default=1, help='NEW: 1 = iid U[-0.5,0.5) clouds (no NTU data here)')
+    p.add_argument('--num_crop', type=int, default=10, help='NEW: views per clip (literal 10 at :189)')
+    p.add_argument('--steps_per_epoch', type=int, default=8, help='NEW: synthetic iterations per epoch')
+    p.add_argument('--group_radius', type=float, default=None,
+                   help='NEW: r^2 of the grouper (default: the reference literals 0.06 at N=512, 0.16 otherwise)')
+    p.add_argument('--log_file', type=str, default='', help='NEW: log path (reference: ../ntu/ntu60_new2/30_0425.log)')
+    return p
+
+
+def synthetic_batch(B, G, N, D, device, generator=None):
+    """(B,G,N,D) float32 iid U[-0.5,0.5), the bench / parity input distribution."""
+    return torch.rand(B, G, N, D, device=device, generator=generator) - 0.5
+
+
+class ContrastiveStep:
+    """One training iteration = the loop body of cn3d_train_motion_GL.py:224-335."""
+
+    def __init__(self, netR, optimizer, opt, num_crop, group_radius=None):
+        self.netR, self.optimizer, self.opt, self.G = netR, optimizer, opt, num_crop
+        self.r2 = group_radius
+        self.rank = torch.distributed.get_rank() if fdist.is_distributed() else 0
+
+    def group(self, data1):
+        opt = self.opt
+        if self.r2 is None and opt.SAMPLE_NUM == 512:
+            return group_points_3DV(data1, opt)                                   # :230 (K=64, r^2=0.06 literals)
+        r2 = self.r2 if self.r2 is not None else 0.16                             # group_points_3DV_2048's literal
+        opt.INPUT_FEATURE_NUM = data1.shape[-1]
+        return knn_radius_group(data1, opt.sample_num_level1, opt.knn_K, r2)
+
+    def __call__(self, out_points, epoch=0, order=None):
+        netR, G = self.netR, self.G
+        B, G_, N, D = out_points.shape
+        data1 = out_points.permute(1, 0, 2, 3).reshape(-1, N, D).float()          # :226-228 (view-major rows)
+        xt, yt = self.group(data1)
+        x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
+        x_keys = fdist.all_gather_view_major(x, G)
+        off = self.rank * B
+        if order is None:
+            order = np.arange(0, G, 1)
+            np.random.shuffle(order)                                               # :297-298
+        loss_c = global_contrast(G, x_global, x, self.opt, x_keys=x_keys, clip_offset=off)          # :265-287
+        loss_circle = circle_contrast(G, x, B, order=order, x_keys=x_keys, clip_offset=off)         # :290-316
+        loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        fdist.allreduce_gradients(netR.parameters())
+        self.optimizer.step()
+        return loss, loss_c, loss_circle
+
+
+def lr_for_epoch(base_lr, epoch, step_size=4, gamma=0.7):
+    """StepLR(4, 0.7) stepped with the explicit epoch every iteration (:181,:333) = closed form."""
+    return base_lr * gamma ** (epoch // step_size)
+
+
+def run(default_branch, ckpt_pattern, args=None):
+    opt = build_parser(default_branch).parse_args(args)
+    print(opt)
+    rank, world = fdist.init_from_env()
+    local = int(os.environ.get("LOCAL_RANK", opt.main_gpu))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    opt.manualSeed = 1
+    random.seed(opt.manualSeed)
+    torch.manual_seed(opt.manualSeed)
+    np.random.seed(opt.manualSeed)          # shared circle-loss permutation across ranks
+    os.makedirs(opt.save_root_dir, exist_ok=True)
+    if opt.log_file:
+        logging.basicConfig(format='%(asctime)s %(message)s', datefmt='%Y/%m/%d %H:%M:%S',
+                            filename=opt.log_file, level=logging.INFO)
+    logging.info('======================================================')
+
+    num_crop = opt.num_crop
+    netR = MODELL.PointNet_Plus(opt, gost=num_crop).to(device)
+    netR.bn_reduce_fn = fdist.make_bn_reduce_fn()
+    optimizer = torch.optim.Adam(netR.parameters(), lr=opt.learning_rate, betas=(0.5, 0.999), eps=1e-06)
+    step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1000 + rank)
+
+    for epoch in range(0, opt.nepoch):
+        netR.train()
+        for g in optimizer.param_groups:
+            g["lr"] = lr_for_epoch(opt.learning_rate, epoch)
+        loss_sigma, t0 = 0.0, time.time()
+        for i in range(opt.steps_per_epoch):
+            if not opt.synthetic:
+                raise RuntimeError("only --synthetic 1 is supported: the NTU dataset pipeline "
+                                   "(cn3D_data_set.py) is outside this repository's scope")
+            out_points = synthetic_batch(opt.batchSize, num_crop, opt.SAMPLE_NUM, opt.INPUT_FEATURE_NUM, device, gen)
+            loss, _, _ = step(out_points, epoch)
+            torch.cuda.synchronize()
+            loss_sigma += loss.item()
+        clips = opt.batchSize * opt.steps_per_epoch * world / (time.time() - t0)
+        logging.info('{} --epoch{} ==Average loss:{}'.format('Valid', epoch, loss_sigma / (i + 1)))
+        if rank == 0:
+            print('epoch:', epoch, 'loss mode is :', 1, '--loss:', loss_sigma / (i + 1), '| clips/s: %.1f' % clips)
+            if epoch % 5 == 0:
+                torch.save(netR.state_dict(), ckpt_pattern % (opt.save_root_dir, epoch))
+    return netR

@@ -70,3 +70,55 @@ def group_points(points, opt):
     opt.INPUT_FEATURE_NUM = points.shape[-1]
     points = points.view(cur_train_size, opt.SAMPLE_NUM, -1)
     return knn_radius_group(points, opt.sample_num_level1, opt.knn_K, opt.ball_radius)
+
+
+# ---- contrastive losses (utils_my.py:53-116 = cn3d_train_motion_GL.py:265-316) -------------------
+def _masked_sim(anchors, keys, anchor_clip, key_clip):
+    """l_neg = (anchors @ keys^T) * mask, mask = 0 where the key belongs to the anchor's own clip
+    (utils_my.py:55-56,71-72).  Same-clip columns are multiplied by 0 -- NOT removed -- so each of them
+    still contributes exp(0) = 1 to the softmax denominator, exactly like the reference."""
+    sim = anchors @ keys.t()
+    same = anchor_clip[:, None] == key_clip[None, :]
+    return torch.where(same, torch.zeros((), dtype=sim.dtype, device=sim.device), sim)
+
+
+def _clip_ids(G, B, device, offset=0):
+    return (torch.arange(B, device=device) + offset).repeat(G)     # row g*B+b -> clip id b
+
+
+def global_contrast(num_crop, x_global, x, opt, criterion=None, x_keys=None, clip_offset=0):
+    """utils_my.py:53-83.  loss_c = sum_g CE([<xg_n, x_{gB+n}> | (xg @ x^T)*mask], 0), CE = mean over B.
+    The (G,B,1+GB) logits tensor and its ``repeat`` are never built: every g shares the negatives, so
+    CE_g[n] = logaddexp(pos[g,n], LSE_n) - pos[g,n].
+
+    Data-parallel form: ``x_keys`` = the all-gathered view-major embeddings (G*B_global rows) and
+    ``clip_offset`` = rank*B_local; anchors stay local (mean over local B, gradients averaged by DDP)."""
+    B, G = x_global.shape[0], num_crop
+    keys = x if x_keys is None else x_keys
+    Bk = keys.shape[0] // G
+    a_clip = torch.arange(B, device=x.device) + clip_offset
+    neg = _masked_sim(x_global, keys, a_clip, _clip_ids(G, Bk, x.device))      # (B, G*Bk)
+    lse = torch.logsumexp(neg, dim=1)
+    pos = (x_global.unsqueeze(0) * x.view(G, B, -1)).sum(-1)                   # (G,B)
+    return (torch.logaddexp(pos, lse.unsqueeze(0)) - pos).mean(dim=1).sum()
+
+
+def circle_contrast(num_crop, x, batchSize, criterion=None, order=None, x_keys=None, clip_offset=0):
+    """utils_my.py:85-116.  ``order`` replaces the reference's np.random.shuffle(arange(num_crop)) (:96-97);
+    when omitted it is drawn from NumPy's global RNG like the reference."""
+    import numpy as np
+    G, B = num_crop, batchSize
+    if order is None:
+        order = np.arange(0, G, 1)
+        np.random.shuffle(order)
+    order = torch.as_tensor(np.asarray(order), device=x.device, dtype=torch.long)
+    keys = x if x_keys is None else x_keys
+    Bk = keys.shape[0] // G
+    xv = x.view(G, B, -1)
+    anchors = xv[order[:-1]]                                                   # (G-1,B,C)
+    pos = (anchors * xv[order[1:]]).sum(-1)                                    # (G-1,B)   :100
+    a_clip = (torch.arange(B, device=x.device) + clip_offset).repeat(G - 1)
+    neg = _masked_sim(anchors.reshape((G - 1) * B, -1), keys, a_clip, _clip_ids(G, Bk, x.device))
+    neg = neg.view(G - 1, B, G * Bk).permute(1, 0, 2).reshape(B, -1)           # all anchors' negatives, shared (:105-109)
+    lse = torch.logsumexp(neg, dim=1)
+    return (torch.logaddexp(pos, lse.unsqueeze(0)) - pos).mean(dim=1).sum()

@@ -1,0 +1,195 @@
+"""GPU parity of the whole encoder + losses + training step (through the reference-shaped host API)
+vs the reference goldens and the fp64 oracle."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, max_rel_rows, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4          # north_star: fp32 features / loss within 1e-4 relative
+# Gradients: the reference's own fp32 gradients sit 5e-3..1e-2 away from the fp64 evaluation of the same
+# graph (near-ties in the 64- and G*64-wide max-pools resolve differently under rounding and re-route
+# whole gradient rows; measured in scratch on C1: net3DV_1.0.weight 7e-3, net3DV_3.4.bias 1e-2).  So the
+# golden (= reference fp32) pins us only to ~2e-2; the tight check is against the fp64 oracle below.
+GTOL = 5e-3
+PRE_BN_BIAS = {"net3DV_1.0.bias", "net3DV_1.3.bias", "net3DV_1.6.bias", "net3DV_3.0.bias",
+               "net3DV_3.3.bias", "net3DV_3.6.bias", "netR_FC.0.bias"}
+
+
+def _opt(D, B, N=512):
+    return SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                           sample_num_level2=64, INPUT_FEATURE_NUM=D, Num_Class=512, batchSize=B,
+                           pooling="concatenation", SAMPLE_NUM=N)
+
+
+def _model(D, B, G, neg=False):
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from oracle.weights import formula_state_dict
+    net = PointNet_Plus(_opt(D, B), gost=G)
+    net.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(D, neg_gamma=neg).items()})
+    return net.to(DEV)
+
+
+def _oracle_forward(g, D, neg, dtype):
+    from oracle import encoder as E, grouping as OG, loss as OL
+    from oracle.weights import formula_state_dict
+    B, G, N, S, K, _ = [int(v) for v in g["meta"]]
+    _, xt, yt = OG.group_points(g["points"], S, K, 0.06)
+    M = G * B
+    sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
+          for k, v in formula_state_dict(D, neg_gamma=neg).items()}
+    with torch.no_grad():
+        x, code, xn, xg = E.encoder_forward(sd, torch.from_numpy(xt).permute(0, 3, 1, 2).to(dtype),
+                                            torch.from_numpy(yt).view(M, 1, S, 3).transpose(1, 3).to(dtype), G, True)
+        lc, lo = float(OL.global_contrast(G, xg, x, B)), float(OL.circle_contrast(G, x, B, g["order"]))
+    return x, code, xn, xg, lc, lo, sd
+
+
+def _oracle_grads(g, D, neg, dtype):
+    from oracle import encoder as E, grouping as OG, loss as OL
+    from oracle.weights import formula_state_dict
+    B, G, N, S, K, _ = [int(v) for v in g["meta"]]
+    _, xt, yt = OG.group_points(g["points"], S, K, 0.06)
+    M = G * B
+    sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
+          for k, v in formula_state_dict(D, neg_gamma=neg).items()}
+    keys = [k for k in sd if "running" not in k and "num_b" not in k]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    x, code, xn, xg = E.encoder_forward(sd, torch.from_numpy(xt).permute(0, 3, 1, 2).to(dtype),
+                                        torch.from_numpy(yt).view(M, 1, S, 3).transpose(1, 3).to(dtype), G, True)
+    (OL.global_contrast(G, xg, x, B) + OL.circle_contrast(G, x, B, g["order"])).backward()
+    return {k: sd[k].grad.numpy() for k in keys if sd[k].grad is not None}
+
+
+@pytest.mark.parametrize("tag,D,neg", [("d4", 4, False), ("d3", 3, False), ("d4_neg", 4, True)])
+def test_c1_golden_forward_loss_backward_adam(tag, D, neg):
+    from facl_amd.utils_my import circle_contrast, global_contrast, group_points_3DV
+    g = load_golden(f"c1_{tag}.npz")
+    B, G, N, S, K, _ = [int(v) for v in g["meta"]]
+    opt = _opt(D, B)
+    pts = torch.from_numpy(g["points"]).to(DEV)
+    xt, yt = group_points_3DV(pts, opt)
+
+    net = _model(D, B, G, neg).eval()
+    with torch.no_grad():
+        ev = net(xt, yt)
+    for name, t in zip(("x", "code", "x_nor", "x_global"), ev):
+        e = max_rel_rows(t.cpu().numpy(), g[f"eval_{name}"])
+        print(f"eval {name}: {e:.2e}")
+        assert e < TOL, name
+
+    net = _model(D, B, G, neg).train()
+    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
+    losses = []
+    for it in range(3):
+        x, code, x_nor, x_global = net(xt, yt, 1)
+        loss_c = global_contrast(G, x_global, x, opt)
+        loss_circle = circle_contrast(G, x, B, order=g["order"])
+        loss = loss_circle + loss_c
+        optim.zero_grad()
+        loss.backward()
+        if it == 0:
+            # Truth = the oracle evaluated in fp64.  The 1e-4 bar is asserted against THAT; the golden is the
+            # reference's own fp32 run, which itself sits up to 8e-4 (c1_d3 x) / 1.5e-3 (x_global) from the
+            # fp64 truth, so against the golden we assert "within the golden's own distance to truth + 1e-4".
+            o64 = _oracle_forward(g, D, neg, torch.float64)
+            for name, t, r64 in zip(("x", "code", "x_nor", "x_global"), (x, code, x_nor, x_global), o64[:4]):
+                mine = t.detach().cpu().numpy()
+                e_truth = max_rel_rows(mine, r64.numpy())
+                e_gold = max_rel_rows(mine, g[f"train_{name}"])
+                gold_noise = max_rel_rows(g[f"train_{name}"], r64.numpy())
+                print(f"train {name}: vs fp64 {e_truth:.2e}  vs golden {e_gold:.2e}  (golden vs fp64 {gold_noise:.2e})")
+                assert e_truth < TOL, name
+                assert e_gold < gold_noise + TOL, name
+            for mine_l, key, r64 in ((loss_c, "loss_c", o64[4]), (loss_circle, "loss_circle", o64[5])):
+                assert abs(mine_l.item() - r64) <= TOL * abs(r64), key
+                assert abs(mine_l.item() - float(g[key])) <= abs(float(g[key]) - r64) + TOL * abs(r64), key
+            g64, g32 = _oracle_grads(g, D, neg, torch.float64), _oracle_grads(g, D, neg, torch.float32)
+            gmax = max(float(g[k]) for k in g if k.startswith("gradnorm/"))
+            for k, p in net.named_parameters():
+                if f"gradnone/{k}" in g:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0
+                    continue
+                mine = p.grad.cpu().numpy()
+                gn = float(g[f"gradnorm/{k}"])
+                if k in PRE_BN_BIAS:
+                    wn = float(g[f"gradnorm/{k[:-4]}weight"])
+                    assert np.linalg.norm(mine) <= 1e-2 * wn, k
+                    continue
+                scale = max(gn, 1e-2 * gmax)
+                # vs the golden (reference fp32): within the golden's own distance to the fp64 truth + margin
+                if f"grad/{k}" in g:
+                    gold_noise = np.linalg.norm(g[f"grad/{k}"] - g64[k])
+                    assert np.linalg.norm(mine - g[f"grad/{k}"]) <= gold_noise + GTOL * scale + 1e-5, k
+                else:
+                    gold_noise = abs(gn - np.linalg.norm(g64[k]))
+                    assert abs(np.linalg.norm(mine.astype(np.float64)) - gn) <= gold_noise + GTOL * scale + 1e-5, k
+            # tight check: at least as close to the fp64 truth as the reference's fp32 arithmetic is
+            for k, p in net.named_parameters():
+                if k in PRE_BN_BIAS or k not in g64 or k == "net3DV_3.7.bias":   # mathematically ~0 gradients
+                    continue
+                e_mine = rel_err(p.grad.cpu().numpy(), g64[k])
+                e_t32 = rel_err(g32[k], g64[k])
+                print(f"grad {k:20s} mine-vs-fp64 {e_mine:.2e}   torch-fp32-vs-fp64 {e_t32:.2e}")
+                # noise floor = max-pool near-tie flips (discrete), it moves with the host's reduction order:
+                # 2e-4 on the GPU box's CPU, 7e-3 in the build container for the SAME oracle code.  The
+                # kernel-level gradient check (same upstream gradient, no flips) is test_gpu_sa_mlp.py: 3e-7.
+                assert e_mine <= max(3 * e_t32, 5e-3), k
+            sd = net.state_dict()
+            for k in sd:
+                if "running_" in k:
+                    r64 = o64[6][k].numpy()
+                    assert rel_err(sd[k].cpu().numpy(), r64) < 1e-5, k
+                    assert rel_err(sd[k].cpu().numpy(), g[f"buf1/{k}"]) < rel_err(g[f"buf1/{k}"], r64) + 1e-5, k
+                if "num_batches" in k:
+                    assert int(sd[k]) == int(g[f"buf1/{k}"]), k
+        optim.step()
+        losses.append(loss.item())
+    print("losses", losses, g["losses3"])
+    l64 = o64[4] + o64[5]
+    assert abs(losses[0] - l64) <= TOL * abs(l64)
+    assert abs(losses[0] - g["losses3"][0]) <= abs(g["losses3"][0] - l64) + TOL * abs(l64)
+    # steps 2-3 inherit the gradient noise floor above through Adam's normalised update (the reference's
+    # fp32 run and its fp64 evaluation diverge by the same amount)
+    np.testing.assert_allclose(losses, g["losses3"], rtol=3e-2)
+
+
+def test_step_vs_fp64_oracle_headline_shapes_small_batch():
+    """N=2048 clouds (the headline cloud size), small batch: the training step through
+    facl_amd.train_common.ContrastiveStep vs the oracle evaluated in fp64 (truth), with the oracle's own
+    fp32 evaluation beside it as the noise floor."""
+    from facl_amd.train_common import ContrastiveStep
+    from oracle import encoder as E, grouping as OG, loss as OL
+    from oracle.weights import formula_state_dict
+    D, B, G, N, S, K = 4, 3, 4, 2048, 64, 64
+    torch.manual_seed(5)
+    clip = torch.rand(B, G, N, D) - 0.5
+    opt = _opt(D, B, N)
+    net = _model(D, B, G).train()
+    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
+    step = ContrastiveStep(net, optim, opt, G)
+    order = np.array([2, 0, 3, 1])
+    loss, loss_c, loss_circle = step(clip.to(DEV), epoch=0, order=order)
+
+    pts = clip.permute(1, 0, 2, 3).reshape(-1, N, D).numpy()
+    _, xt, yt = OG.group_points(pts, S, K, 0.16)
+    M = G * B
+
+    def ref(dtype):
+        sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
+              for k, v in formula_state_dict(D).items()}
+        with torch.no_grad():
+            x, code, x_nor, xg = E.encoder_forward(sd, torch.from_numpy(xt).permute(0, 3, 1, 2).to(dtype),
+                                                   torch.from_numpy(yt).view(M, 1, S, 3).transpose(1, 3).to(dtype),
+                                                   G, training=True)
+            return float(OL.global_contrast(G, xg, x, B) + OL.circle_contrast(G, x, B, order))
+
+    l64, l32 = ref(torch.float64), ref(torch.float32)
+    e_mine, e_t32 = abs(loss.item() - l64) / abs(l64), abs(l32 - l64) / abs(l64)
+    print(f"loss: mine {loss.item():.6f} fp64 {l64:.6f}  rel {e_mine:.2e}   torch-fp32 rel {e_t32:.2e}")
+    assert e_mine < TOL

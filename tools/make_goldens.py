@@ -209,10 +209,26 @@ def run_c1(D, neg_gamma, tag):
     print(f"c1_{tag}.npz losses", losses)
 
 
+def make_init():
+    """Default initialisation of the reference model under torch.manual_seed(1) (cn3d_train_motion_GL.py:142-144,173):
+    per-key fingerprints, so the test can check that facl_amd's constructor draws the same weights."""
+    out = {}
+    for D in (3, 4):
+        opt = ref_opt(4, 512, 64, 64, D)
+        torch.manual_seed(1)
+        net = R_model.PointNet_Plus(opt)
+        for k, v in net.state_dict().items():
+            a = v.detach().numpy().astype(np.float64).reshape(-1)
+            out[f"D{D}/{k}"] = np.concatenate(([a.size, a.sum(), np.abs(a).sum()], a[:8]))
+    np.savez_compressed(os.path.join(OUT, "init.npz"), **out)
+    print("init.npz", len(out))
+
+
 def main():
     argparse.ArgumentParser(description=__doc__).parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    make_init()
     make_fps()
     make_tiny()
     run_c1(4, False, "d4")

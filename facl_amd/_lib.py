@@ -36,6 +36,13 @@ SIGNATURES = {
     "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_rows_stats": [c_p, c_l, c_i, c_p, c_p, c_p],
+    "facl_rows_bn_relu": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_rows_segmax": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
+    "facl_rows_bwd_stats": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_rows_bwd_apply": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_segmax_bwd_stats": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
+    "facl_segmax_bwd_apply": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "facl_sa_bwd0": [c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_bwd1": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_bwd_w3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p],

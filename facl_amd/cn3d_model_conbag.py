@@ -139,11 +139,14 @@ class PointNet_Plus(nn.Module):
                 self.net3DV_1[i].num_batches_tracked += 1
 
         h = torch.cat((centers, pooled), 1)                                    # :219
-        for li in (0, 3, 6):                                                   # net3DV_3 (:220)
+        for li in (0, 3):                                                      # net3DV_3 (:220)
             h = _tail.linear_bn_relu(h, self.net3DV_3[li], self.net3DV_3[li + 1], training, self.bn_reduce_fn)
-        x_pre = h.view(M, S, 1024).amax(dim=1)                                 # :222-223
+        # last layer fused with my_max_pool (:222-223): xt_local (M,1024,S,1) is never materialised post-BN
+        x_pre = _tail.linear_bn_relu_segmax(h, self.net3DV_3[6], self.net3DV_3[7], training, S, self.bn_reduce_fn)
         Bc = M // self.gost
-        xg_pre = h.view(self.gost, Bc, S, 1024).amax(dim=2).amax(dim=0)        # :225-226 (rows g*B+b)
+        # gobaol_max_pool over all gost*S local features of a clip (:225-226) = max over the gost views of
+        # the per-view maxima (rows are view-major: g*B+b)
+        xg_pre = x_pre.view(self.gost, Bc, 1024).max(dim=0).values
         x = self._fc(x_pre, training)                                          # :228
         x_global = self._fc(xg_pre, training)                                  # :229 (second BN statistics update)
         x_nor = F.normalize(x, p=2, dim=1)                                     # :231
@@ -153,7 +156,7 @@ class PointNet_Plus(nn.Module):
     def _fc(self, v, training):
         fc = self.netR_FC
         v = _tail.linear_bn_relu(v, fc[0], fc[1], training, self.bn_reduce_fn)
-        return F.linear(v, fc[3].weight, fc[3].bias)
+        return torch.addmm(fc[3].bias, v, fc[3].weight.t())
 
 
 class PointNet_Plus_fine(PointNet_Plus):

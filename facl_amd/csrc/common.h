@@ -40,6 +40,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // D[i][j] += A[i][0..1] * B[0..1][j]; lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // D: lane l holds column j = l&31, rows rowmap(r, l>>5), r = 0..15.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -6,18 +6,29 @@
 
 namespace {
 
-// part[rows][V] -> out[V]  (deterministic: fixed order, no atomics)
-__global__ void k_reduce_rows(const double* __restrict__ part, int rows, int V, double* __restrict__ out) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-        s0 += part[(size_t)r * V + v]; s1 += part[(size_t)(r + 1) * V + v];
-        s2 += part[(size_t)(r + 2) * V + v]; s3 += part[(size_t)(r + 3) * V + v];
+// part[rows][V] -> out[V]  (deterministic: fixed order, no atomics).  Block = 64 columns x 16 row groups.
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ part, int rows, int V,
+                                                      double* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int v = blockIdx.x * 64 + col;
+    double s0 = 0, s1 = 0;
+    if (v < V) {
+        int r = rg;
+        for (; r + 16 < rows; r += 32) {
+            s0 += part[(size_t)r * V + v];
+            s1 += part[(size_t)(r + 16) * V + v];
+        }
+        if (r < rows) s0 += part[(size_t)r * V + v];
     }
-    for (; r < rows; ++r) s0 += part[(size_t)r * V + v];
-    out[v] = (s0 + s1) + (s2 + s3);
+    red[rg][col] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && v < V) {
+        double t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][col];
+        out[v] = t;
+    }
 }
 
 __global__ void k_bn_finalize(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
@@ -93,7 +104,7 @@ __global__ void k_l1tab(const float* __restrict__ W1, const float* __restrict__ 
 }  // namespace
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_rows, dim3((V + 63) / 64), dim3(64), 0, st, part, rows, V, out);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((V + 63) / 64), dim3(1024), 0, st, part, rows, V, out);
     return facl_launch_status();
 }
 

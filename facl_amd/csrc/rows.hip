@@ -1,0 +1,222 @@
+// Row-major (R,C) activation kernels of the encoder tail (net3DV_3 / netR_FC, cn3d_model_conbag.py:61-88):
+// train-mode BatchNorm statistics, BN+ReLU apply, BN+ReLU+max-over-S (my_max_pool :80/:199), and their
+// backward passes.  All HBM-bound streaming kernels (float4 per lane, channels fastest).
+// Algorithmic bytes: stats R*C*4 read; apply 2*R*C*4; segmax R*C*4 read; bwd_stats 2*R*C*4 read;
+// bwd_apply 3*R*C*4; bwd_sparse 2*R*C*4.
+#include "common.h"
+
+int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+
+namespace {
+
+constexpr int ROWS_BLOCKS = 1024;     // row-slices of the grid (partial rows in ws)
+
+// consts layout "bnc": (5,C) = mean, invstd, scale, shift, sgn   (facl_bn_finalize)
+
+// ---- column sums / sums of squares -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_stats(const float* __restrict__ y, int R, int C,
+                                                    double* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+        const float v = y[(size_t)r * C + c];
+        s += (double)v;
+        q += (double)v * (double)v;
+    }
+    part[(size_t)blockIdx.y * 2 * C + 2 * c] = s;
+    part[(size_t)blockIdx.y * 2 * C + 2 * c + 1] = q;
+}
+
+// ---- out = relu(scale*y + shift) ------------------------------------------------------------------
+__global__ void k_rows_bn_relu(const float* __restrict__ y, long long n4, int C4, const float* __restrict__ scale,
+                               const float* __restrict__ shift, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int c4 = (int)(i % C4);
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+        float4 o;
+        o.x = fmaxf(fmaf(sc.x, v.x, sh.x), 0.f); o.y = fmaxf(fmaf(sc.y, v.y, sh.y), 0.f);
+        o.z = fmaxf(fmaf(sc.z, v.z, sh.z), 0.f); o.w = fmaxf(fmaf(sc.w, v.w, sh.w), 0.f);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
+// ---- x_pre[m,c] = max_s relu(bn(y[m,s,c])) = relu(|scale| * max_s(sgn*y) + shift), first max wins ----
+__global__ __launch_bounds__(256) void k_rows_segmax(const float* __restrict__ y, int S, int C,
+                                                     const float* __restrict__ bnc, float* __restrict__ out,
+                                                     int* __restrict__ arg) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (c >= C) return;
+    const float scale = bnc[2 * C + c], shift = bnc[3 * C + c], sgn = bnc[4 * C + c];
+    const float* base = y + (size_t)m * S * C + c;
+    float best = sgn * base[0];
+    int bi = 0;
+    for (int s = 1; s < S; ++s) {
+        const float v = sgn * base[(size_t)s * C];
+        if (v > best) { best = v; bi = s; }
+    }
+    out[(size_t)m * C + c] = fmaxf(fmaf(fabsf(scale), best, shift), 0.f);
+    arg[(size_t)m * C + c] = bi;
+}
+
+// ---- backward of relu(bn(y)): sums of dz = dout*[z>0] and dz*yhat ---------------------------------
+__global__ __launch_bounds__(256) void k_rows_bwd_stats(const float* __restrict__ dout, const float* __restrict__ y,
+                                                        int R, int C, const float* __restrict__ bnc,
+                                                        double* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mean = bnc[c], inv = bnc[C + c], scale = bnc[2 * C + c], shift = bnc[3 * C + c];
+    double s = 0, g = 0;
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+        const float v = y[(size_t)r * C + c];
+        const float d = fmaf(scale, v, shift) > 0.f ? dout[(size_t)r * C + c] : 0.f;
+        s += (double)d;
+        g += (double)d * (double)((v - mean) * inv);
+    }
+    part[(size_t)blockIdx.y * 2 * C + 2 * c] = s;
+    part[(size_t)blockIdx.y * 2 * C + 2 * c + 1] = g;
+}
+
+// dy = scale * (dz - k1 - yhat*k2),  kk = (2,C): k1 = dbeta/P, k2 = dgamma/P
+__global__ void k_rows_bwd_apply(const float* __restrict__ dout, const float* __restrict__ y, long long n, int C,
+                                 const float* __restrict__ bnc, const float* __restrict__ kk,
+                                 float* __restrict__ dy) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % C);
+        const float mean = bnc[c], inv = bnc[C + c], scale = bnc[2 * C + c], shift = bnc[3 * C + c];
+        const float v = y[i];
+        const float d = fmaf(scale, v, shift) > 0.f ? dout[i] : 0.f;
+        dy[i] = scale * (d - kk[c] - (v - mean) * inv * kk[C + c]);
+    }
+}
+
+// ---- backward through the max over S (+ BN + ReLU): sparse sums, then the dense dy -----------------
+// dz[m,c] = dxpre[m,c] * [xpre > 0] lives at row arg[m,c]; yhat there = (y_at_arg - mean)*inv.
+__global__ __launch_bounds__(256) void k_segmax_bwd_stats(const float* __restrict__ dxpre, const float* __restrict__ xpre,
+                                                          const float* __restrict__ y, const int* __restrict__ arg,
+                                                          int Mrows, int S, int C, const float* __restrict__ bnc,
+                                                          double* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mean = bnc[c], inv = bnc[C + c];
+    double s = 0, g = 0;
+    for (int m = blockIdx.y; m < Mrows; m += gridDim.y) {
+        const size_t o = (size_t)m * C + c;
+        const float d = xpre[o] > 0.f ? dxpre[o] : 0.f;
+        const float v = y[((size_t)m * S + arg[o]) * C + c];
+        s += (double)d;
+        g += (double)d * (double)((v - mean) * inv);
+    }
+    part[(size_t)blockIdx.y * 2 * C + 2 * c] = s;
+    part[(size_t)blockIdx.y * 2 * C + 2 * c + 1] = g;
+}
+
+__global__ __launch_bounds__(256) void k_segmax_bwd_apply(const float* __restrict__ dxpre, const float* __restrict__ xpre,
+                                                          const float* __restrict__ y, const int* __restrict__ arg,
+                                                          int S, int C, const float* __restrict__ bnc,
+                                                          const float* __restrict__ kk, float* __restrict__ dy) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (c >= C) return;
+    const float mean = bnc[c], inv = bnc[C + c], scale = bnc[2 * C + c];
+    const float k1 = kk[c], k2 = kk[C + c];
+    const size_t o = (size_t)m * C + c;
+    const float d = xpre[o] > 0.f ? dxpre[o] : 0.f;
+    const int a = arg[o];
+    const float* yb = y + (size_t)m * S * C + c;
+    float* db = dy + (size_t)m * S * C + c;
+    for (int s = 0; s < S; ++s) {
+        const float v = yb[(size_t)s * C];
+        db[(size_t)s * C] = scale * ((s == a ? d : 0.f) - k1 - (v - mean) * inv * k2);
+    }
+}
+
+int rows_grid_y(int R, int C) {
+    int gx = (C + 255) / 256;
+    int gy = ROWS_BLOCKS / gx;
+    if (gy > R) gy = R;
+    if (gy < 1) gy = 1;
+    return gy;
+}
+
+}  // namespace
+
+extern "C" int facl_rows_stats(const float* y, int64_t R, int C, double* sums, void* ws, void* stream) {
+    if (!y || !sums || !ws) return FACL_E_NULL;
+    if (R < 1 || R > 0x7fffffff || C < 1 || 2 * C > 4608) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int gy = rows_grid_y((int)R, C);
+    hipLaunchKernelGGL(k_rows_stats, dim3((C + 255) / 256, gy), dim3(256), 0, st, y, (int)R, C, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, gy, 2 * C, sums, st);
+}
+
+extern "C" int facl_rows_bn_relu(const float* y, int64_t R, int C, const float* scale, const float* shift, float* out,
+                                 void* stream) {
+    if (!y || !scale || !shift || !out) return FACL_E_NULL;
+    if (R < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
+    const long long n4 = R * (long long)(C / 4);
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_rows_bn_relu, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, n4, C / 4, scale, shift, out);
+    return facl_launch_status();
+}
+
+extern "C" int facl_rows_segmax(const float* y, int64_t M, int S, int C, const float* bnc, float* out, int32_t* arg,
+                                void* stream) {
+    if (!y || !bnc || !out || !arg) return FACL_E_NULL;
+    if (M < 1 || M > 65535 || S < 1 || C < 1) return FACL_E_SHAPE;
+    hipLaunchKernelGGL(k_rows_segmax, dim3((C + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, y, S, C, bnc,
+                       out, arg);
+    return facl_launch_status();
+}
+
+extern "C" int facl_rows_bwd_stats(const float* dout, const float* y, int64_t R, int C, const float* bnc, double* sums,
+                                   void* ws, void* stream) {
+    if (!dout || !y || !bnc || !sums || !ws) return FACL_E_NULL;
+    if (R < 1 || R > 0x7fffffff || C < 1 || 2 * C > 4608) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int gy = rows_grid_y((int)R, C);
+    hipLaunchKernelGGL(k_rows_bwd_stats, dim3((C + 255) / 256, gy), dim3(256), 0, st, dout, y, (int)R, C, bnc,
+                       (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, gy, 2 * C, sums, st);
+}
+
+extern "C" int facl_rows_bwd_apply(const float* dout, const float* y, int64_t R, int C, const float* bnc,
+                                   const float* kk, float* dy, void* stream) {
+    if (!dout || !y || !bnc || !kk || !dy) return FACL_E_NULL;
+    if (R < 1 || C < 1) return FACL_E_SHAPE;
+    const long long n = R * (long long)C;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_rows_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, y, n, C, bnc, kk, dy);
+    return facl_launch_status();
+}
+
+extern "C" int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
+                                     int64_t M, int S, int C, const float* bnc, double* sums, void* ws, void* stream) {
+    if (!dxpre || !xpre || !y || !arg || !bnc || !sums || !ws) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || S < 1 || C < 1 || 2 * C > 4608) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int gy = rows_grid_y((int)M, C);
+    hipLaunchKernelGGL(k_segmax_bwd_stats, dim3((C + 255) / 256, gy), dim3(256), 0, st, dxpre, xpre, y, arg, (int)M, S,
+                       C, bnc, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, gy, 2 * C, sums, st);
+}
+
+extern "C" int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
+                                     int64_t M, int S, int C, const float* bnc, const float* kk, float* dy,
+                                     void* stream) {
+    if (!dxpre || !xpre || !y || !arg || !bnc || !kk || !dy) return FACL_E_NULL;
+    if (M < 1 || M > 65535 || S < 1 || C < 1) return FACL_E_SHAPE;
+    hipLaunchKernelGGL(k_segmax_bwd_apply, dim3((C + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, dxpre,
+                       xpre, y, arg, S, C, bnc, kk, dy);
+    return facl_launch_status();
+}

@@ -1,64 +1,139 @@
-"""Encoder tail (net3DV_3, netR_FC: cn3d_model_conbag.py:61-88) -- ROUND-1 INTERIM.
+"""Encoder tail (net3DV_3, my_max_pool, netR_FC: cn3d_model_conbag.py:61-88, :199-207).
 
-The per-centroid MLP and the FC head are plain dense GEMMs + train-mode BN over rows.  In this
-round they run as rocBLAS GEMMs (torch.mm) with the BN reduce/apply written so that the
-statistics are explicit (sum, sumsq) buffers that a SyncBN all-reduce can hook, exactly like the
-HIP passes of sa_mlp.py; the fused MFMA GEMM (BN+ReLU prologue, statistics / segment-max
-epilogue) that replaces them is the next kernel on the list ("what comes next").
+Per layer: one plain library GEMM (rocBLAS via torch.mm -- the 1x1 conv over (M*S) centroid rows IS a
+dense GEMM) + hand-written HIP kernels for everything around it: train-mode BN statistics (fp64 sums,
+SyncBN hook), BN+ReLU apply, BN+ReLU+max over the S centroids without materialising the activation,
+and the matching backward passes (csrc/rows.hip).
 """
 import torch
 
-BN_EPS = 1e-5
-BN_MOMENTUM = 0.1
+from . import _lib
+from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
 
 
-class _BNRows(torch.autograd.Function):
-    """Train-mode BatchNorm over the rows of (R,C) with explicit fp64 statistics; SyncBN-ready."""
+def _stats(y, ws):
+    lib = _lib.load_library()
+    R, C = y.shape
+    sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+    _lib.check(lib.facl_rows_stats(_lib.ptr(y), R, C, _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_rows_stats")
+    return sums
+
+
+def _forward_bn_consts(y, bn, training, reduce_fn, ws):
+    """Statistics -> (5,C) constants; updates running stats / num_batches_tracked in training mode."""
+    R, C = y.shape
+    if not training:
+        return _bn_eval(C, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var), float(R)
+    sums = _stats(y, ws)
+    count = float(R)
+    if reduce_fn is not None:
+        packed = torch.cat([sums.reshape(-1), torch.tensor([count], dtype=torch.float64, device=y.device)])
+        reduce_fn(packed)
+        sums, count = packed[:-1].view(C, 2), float(packed[-1].item())
+    bnc = _bn_finalize(sums, C, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
+    bn.num_batches_tracked += 1
+    return bnc, count
+
+
+class _LinearBNReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, W, b, gamma, beta, bn, training, reduce_fn):
+        lib = _lib.load_library()
+        _lib.require_cuda(h)
+        ws = _Workspace.get(h.device)
+        h = h.contiguous()
+        y = torch.addmm(b, h, W.t())                                   # library GEMM
+        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws)
+        R, C = y.shape
+        a = torch.empty_like(y)
+        _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y), R, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a),
+                                         _lib.stream()), "facl_rows_bn_relu")
+        ctx.save_for_backward(h, W, y, bnc)
+        ctx.count, ctx.reduce_fn, ctx.training = count, reduce_fn, training
+        return a
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, reduce_fn):
-        R = y.shape[0]
-        st = torch.stack([y.sum(0, dtype=torch.float64), (y.double() * y.double()).sum(0),
-                          torch.full((y.shape[1],), float(R), dtype=torch.float64, device=y.device)])
-        if reduce_fn is not None:
-            reduce_fn(st)
-        n = st[2, 0]
-        mean = st[0] / n
-        var = (st[1] / n - mean * mean).clamp_min(0)
-        invstd = torch.rsqrt(var + BN_EPS)
-        with torch.no_grad():
-            unb = var * (n / (n - 1)) if float(n) > 1 else var
-            running_mean.mul_(1 - BN_MOMENTUM).add_(mean.float(), alpha=BN_MOMENTUM)
-            running_var.mul_(1 - BN_MOMENTUM).add_(unb.float(), alpha=BN_MOMENTUM)
-        scale = (gamma.double() * invstd).float()
-        shift = (beta.double() - mean * gamma.double() * invstd).float()
-        out = torch.addcmul(shift, y, scale)
-        ctx.save_for_backward(y, gamma, mean.float(), invstd.float())
-        ctx.reduce_fn, ctx.n = reduce_fn, float(n)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        y, gamma, mean, invstd = ctx.saved_tensors
-        yhat = (y - mean) * invstd
-        sums = torch.stack([dout.sum(0, dtype=torch.float64), (dout.double() * yhat.double()).sum(0)])
-        dbeta_l, dgamma_l = sums[0].float(), sums[1].float()
+    def backward(ctx, da):
+        if not ctx.training:
+            raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
+        lib = _lib.load_library()
+        h, W, y, bnc = ctx.saved_tensors
+        ws = _Workspace.get(y.device)
+        R, C = y.shape
+        da = da.contiguous()
+        sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+        _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws),
+                                           _lib.stream()), "facl_rows_bwd_stats")
+        dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()          # parameter gradients stay local
         if ctx.reduce_fn is not None:
             ctx.reduce_fn(sums)
-        k1 = (sums[0] / ctx.n).float()
-        k2 = (sums[1] / ctx.n).float()
-        dy = (dout - k1 - yhat * k2) * (gamma * invstd)
-        return dy, dgamma_l, dbeta_l, None, None, None
+        kk = (sums.t() / ctx.count).float().contiguous()               # (2,C): dbeta/P, dgamma/P
+        dy = torch.empty_like(y)
+        _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
+                                           _lib.stream()), "facl_rows_bwd_apply")
+        dW = dy.t() @ h                                                 # library GEMMs
+        dh = dy @ W if ctx.needs_input_grad[0] else None
+        return dh, dW, torch.zeros_like(dbeta), dgamma, dbeta, None, None, None
+
+
+class _LinearBNSegmax(torch.autograd.Function):
+    """x_pre = max over the S centroids of relu(bn(h W^T + b)) -- cn3d_model_conbag.py:71-73 + :199/:222."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, gamma, beta, bn, training, reduce_fn, S):
+        lib = _lib.load_library()
+        _lib.require_cuda(h)
+        ws = _Workspace.get(h.device)
+        h = h.contiguous()
+        y = torch.addmm(b, h, W.t())
+        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws)
+        R, C = y.shape
+        M = R // S
+        xpre = torch.empty((M, C), dtype=torch.float32, device=y.device)
+        arg = torch.empty((M, C), dtype=torch.int32, device=y.device)
+        _lib.check(lib.facl_rows_segmax(_lib.ptr(y), M, S, C, _lib.ptr(bnc), _lib.ptr(xpre), _lib.ptr(arg), _lib.stream()),
+                   "facl_rows_segmax")
+        ctx.save_for_backward(h, W, y, bnc, xpre, arg)
+        ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
+        ctx.mark_non_differentiable(arg)
+        return xpre, arg
+
+    @staticmethod
+    def backward(ctx, dxpre, _darg):
+        if not ctx.training:
+            raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
+        lib = _lib.load_library()
+        h, W, y, bnc, xpre, arg = ctx.saved_tensors
+        ws = _Workspace.get(y.device)
+        R, C = y.shape
+        S = ctx.S
+        M = R // S
+        dxpre = dxpre.contiguous()
+        sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+        _lib.check(lib.facl_segmax_bwd_stats(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
+                                             _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
+                   "facl_segmax_bwd_stats")
+        dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()
+        if ctx.reduce_fn is not None:
+            ctx.reduce_fn(sums)
+        kk = (sums.t() / ctx.count).float().contiguous()
+        dy = torch.empty_like(y)
+        _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
+                                             _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), _lib.stream()),
+                   "facl_segmax_bwd_apply")
+        dW = dy.t() @ h
+        dh = dy @ W
+        return dh, dW, torch.zeros_like(dbeta), dgamma, dbeta, None, None, None, None
 
 
 def linear_bn_relu(h, affine, bn, training, reduce_fn=None):
     """relu(bn(h W^T + b)) over rows; W is (Cout,Cin[,1,1])."""
     W = affine.weight.view(affine.weight.shape[0], -1)
-    y = torch.addmm(affine.bias, h, W.t())
-    if training:
-        y = _BNRows.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, reduce_fn)
-        bn.num_batches_tracked += 1
-    else:
-        invstd = torch.rsqrt(bn.running_var + BN_EPS)
-        y = (y - bn.running_mean) * (invstd * bn.weight) + bn.bias
-    return torch.relu(y)
+    return _LinearBNReLU.apply(h, W, affine.bias, bn.weight, bn.bias, bn, training, reduce_fn)
+
+
+def linear_bn_relu_segmax(h, affine, bn, training, S, reduce_fn=None):
+    """(M*S,Cin) -> (M,Cout): the last per-centroid layer fused with the max over each cloud's S centroids."""
+    W = affine.weight.view(affine.weight.shape[0], -1)
+    xpre, _ = _LinearBNSegmax.apply(h, W, affine.bias, bn.weight, bn.bias, bn, training, reduce_fn, S)
+    return xpre

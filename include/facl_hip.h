@@ -129,6 +129,31 @@ int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nu
                  const float* bw2, const float* W2, const float* l1tab, double* out, void* ws,
                  void* stream);
 
+/* ---- encoder tail: row-major (R,C) BatchNorm / ReLU / max-over-S kernels ----------------------
+ * net3DV_3 + my_max_pool + netR_FC (cn3d_model_conbag.py:61-88, :199-207).  The dense contractions
+ * between them are plain library GEMMs (rocBLAS through torch.mm); these kernels are everything else.
+ * bnc = (5,C) constants of facl_bn_finalize / facl_bn_eval_consts; kk = (2,C) = (dbeta/P, dgamma/P).
+ *   facl_rows_stats        y (R,C) -> sums (C,2)
+ *   facl_rows_bn_relu      out = relu(scale*y + shift)                         (may run in place)
+ *   facl_rows_segmax       x_pre[m,c] = max_s relu(bn(y[m,s,c])), arg = first maximising s
+ *   facl_rows_bwd_stats    sums (C,2) = (sum dz, sum dz*yhat), dz = dout*[bn(y) > 0]
+ *   facl_rows_bwd_apply    dy = scale*(dz - k1 - yhat*k2)
+ *   facl_segmax_bwd_stats / _apply : the same two steps for the gradient arriving through the max over S
+ */
+int facl_rows_stats(const float* y, int64_t R, int C, double* sums, void* ws, void* stream);
+int facl_rows_bn_relu(const float* y, int64_t R, int C, const float* scale, const float* shift, float* out,
+                      void* stream);
+int facl_rows_segmax(const float* y, int64_t M, int S, int C, const float* bnc, float* out, int32_t* arg,
+                     void* stream);
+int facl_rows_bwd_stats(const float* dout, const float* y, int64_t R, int C, const float* bnc, double* sums,
+                        void* ws, void* stream);
+int facl_rows_bwd_apply(const float* dout, const float* y, int64_t R, int C, const float* bnc,
+                        const float* kk, float* dy, void* stream);
+int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
+                          int64_t M, int S, int C, const float* bnc, double* sums, void* ws, void* stream);
+int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
+                          int64_t M, int S, int C, const float* bnc, const float* kk, float* dy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

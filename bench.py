@@ -117,7 +117,8 @@ def main():
     a = parse()
     from facl_amd import dist as fdist
     rank, world = fdist.init_from_env()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; `% device_count` only matters when rehearsing N>1 on a single-GPU box
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from facl_amd.cn3d_model_conbag import PointNet_Plus

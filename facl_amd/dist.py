@@ -25,7 +25,8 @@ def init_from_env(backend=None):
         return 0, world if dist.is_initialized() else 1
     rank = int(os.environ["RANK"])
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # "nccl" IS RCCL on ROCm.  FACL_DIST_BACKEND=gloo rehearses the N>1 path on a single-GPU box.
+        backend = os.environ.get("FACL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 

@@ -1,0 +1,84 @@
+"""world_size-2 rehearsal of the data-parallel step on ONE GPU (gloo collectives, both ranks on cuda:0):
+the sharded step (SyncBN hooks inside the HIP passes, embeddings all-gather, flat gradient all-reduce) must
+equal the single-process step at the global batch."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opt(D, B, N):
+    return SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                           sample_num_level2=64, INPUT_FEATURE_NUM=D, Num_Class=512, batchSize=B,
+                           pooling="concatenation", SAMPLE_NUM=N)
+
+
+def _run_step(clip, G, rank, world):
+    from facl_amd import dist as fdist
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.train_common import ContrastiveStep
+    from oracle.weights import formula_state_dict
+    B, _, N, D = clip.shape
+    opt = _opt(D, B, N)
+    net = PointNet_Plus(opt, gost=G)
+    net.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(D).items()})
+    net = net.cuda().train()
+    net.bn_reduce_fn = fdist.make_bn_reduce_fn()
+    optim = torch.optim.SGD(net.parameters(), lr=0.0)            # keep the parameters: we compare gradients
+    step = ContrastiveStep(net, optim, opt, G)
+    loss, _, _ = step(clip.cuda(), epoch=0, order=np.array([2, 0, 3, 1]))
+    grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+    bufs = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k}
+    return float(loss.item()), grads, bufs
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      FACL_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from facl_amd import dist as fdist
+    torch.cuda.set_device(0)
+    fdist.init_from_env()
+    torch.manual_seed(3)
+    G, Bl, N, D = 4, 2, 512, 4
+    full = torch.rand(Bl * world, G, N, D) - 0.5
+    loss, grads, bufs = _run_step(full[rank * Bl:(rank + 1) * Bl], G, rank, world)
+    q.put((rank, loss, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in bufs.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_global_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    # single process, global batch
+    torch.manual_seed(3)
+    G, Bl, N, D = 4, 2, 512, 4
+    full = torch.rand(Bl * 2, G, N, D) - 0.5
+    loss1, grads1, bufs1 = _run_step(full, G, 0, 1)
+    loss2 = 0.5 * (res[0][1] + res[1][1])                         # mean of the per-rank (local-mean) losses
+    print("loss 1-rank %.6f  2-rank %.6f" % (loss1, loss2))
+    assert abs(loss1 - loss2) <= 1e-5 * abs(loss1)
+    gmax = max(float(np.linalg.norm(v.numpy())) for v in grads1.values())
+    for k, g1 in grads1.items():
+        g1 = g1.numpy()
+        for r in (0, 1):                                          # after the averaged all-reduce both ranks agree
+            g2 = res[r][2][k]
+            assert np.linalg.norm(g2 - g1) <= 2e-4 * max(np.linalg.norm(g1), 1e-2 * gmax) + 1e-6, (k, r)
+    for k, b1 in bufs1.items():                                   # SyncBN: running statistics of the GLOBAL batch
+        assert np.allclose(res[0][3][k], b1.numpy(), rtol=2e-5, atol=1e-7), k

@@ -112,7 +112,11 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
                 const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfv[t & 3]), src));
                 const int ps = __builtin_amdgcn_readlane(arv[t & 3], src);
                 const float v = cf * w[t];
-                if (ps < 32) srow0[ps] += v; else srow1[ps - 32] += v;      // uniform branch + GPR-indexed RMW
+                // branch-free: a uniform `if` makes the compiler copy the whole 32-register vector per element
+                const bool lo = ps < 32;
+                const int pi = ps & 31;
+                srow0[pi] += lo ? v : 0.f;
+                srow1[pi] += lo ? 0.f : v;
             }
         }
 #pragma unroll

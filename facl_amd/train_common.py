@@ -11,7 +11,7 @@ import torch
 
 from . import cn3d_model_conbag as MODELL
 from . import dist as fdist
-from .utils_my import circle_contrast, global_contrast, group_points_3DV, knn_radius_group
+from .utils_my import contrastive_losses, group_points_3DV, knn_radius_group
 
 
 def build_parser(default_branch):
@@ -94,8 +94,8 @@ class ContrastiveStep:
         if order is None:
             order = np.arange(0, G, 1)
             np.random.shuffle(order)                                               # :297-298
-        loss_c = global_contrast(G, x_global, x, self.opt, x_keys=x_keys, clip_offset=off)          # :265-287
-        loss_circle = circle_contrast(G, x, B, order=order, x_keys=x_keys, clip_offset=off)         # :290-316
+        # global (:265-287) + circle (:290-316) losses: similarity GEMMs + one HIP kernel each (csrc/loss.hip)
+        loss_c, loss_circle = contrastive_losses(G, x_global, x, order, x_keys=x_keys, clip_offset=off)
         loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()

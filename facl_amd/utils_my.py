@@ -122,3 +122,63 @@ def circle_contrast(num_crop, x, batchSize, criterion=None, order=None, x_keys=N
     neg = neg.view(G - 1, B, G * Bk).permute(1, 0, 2).reshape(B, -1)           # all anchors' negatives, shared (:105-109)
     lse = torch.logsumexp(neg, dim=1)
     return (torch.logaddexp(pos, lse.unsqueeze(0)) - pos).mean(dim=1).sum()
+
+
+# ---- fused HIP path for both losses (csrc/loss.hip): 2 library GEMMs + one kernel per loss ------------
+class _ContrastiveLosses(torch.autograd.Function):
+    """(loss_c, loss_circle) with the value and d/dsim computed by facl_contrast; the similarity GEMMs and
+    their transposes in the backward are plain library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x_global, x, x_keys, order, G, clip_offset):
+        from .sa_mlp import _Workspace
+        lib = _lib.load_library()
+        _lib.require_cuda(x, x_global, x_keys)
+        dev = x.device
+        ws = _Workspace.get(dev)
+        B, C = x_global.shape
+        Bk = x_keys.shape[0] // G
+        J = G * Bk
+        xg = x_global.contiguous()
+        keys = x_keys.contiguous()
+        xv = x.view(G, B, C)
+        anchors = xv[order[:-1]].reshape((G - 1) * B, C).contiguous()              # circle anchors (:100,:103)
+        n_idx = torch.arange(B, device=dev, dtype=torch.int32) + clip_offset
+        g_idx = torch.arange(G, device=dev, dtype=torch.int32)
+        pos_g = (g_idx[:, None] * Bk + n_idx[None, :]).reshape(-1)                  # global: sim_g is (B,J); slots = views
+        pos_c = (order[1:].to(torch.int32)[:, None] * Bk + n_idx[None, :]).reshape(-1).contiguous()
+        sim_c = anchors @ keys.t()                                                 # ((G-1)B, J)  :103
+        sim_g = xg @ keys.t()                                                      # (B, J)       :71
+        dsim_g = torch.empty_like(sim_g)
+        dsim_c = torch.empty_like(sim_c)
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        st = _lib.stream()
+        _lib.check(lib.facl_contrast(_lib.ptr(sim_g), B, J, B, Bk, 1, G, 0, _lib.ptr(pos_g.contiguous()), clip_offset,
+                                     _lib.ptr(dsim_g), out[0:1].data_ptr(), _lib.ptr(ws), st), "facl_contrast(global)")
+        _lib.check(lib.facl_contrast(_lib.ptr(sim_c), (G - 1) * B, J, B, Bk, G - 1, G - 1, 1, _lib.ptr(pos_c), clip_offset,
+                                     _lib.ptr(dsim_c), out[1:2].data_ptr(), _lib.ptr(ws), st), "facl_contrast(circle)")
+        ctx.save_for_backward(xg, keys, anchors, dsim_g, dsim_c, order)
+        ctx.dims = (G, B, C, J)
+        return out[0].float(), out[1].float()
+
+    @staticmethod
+    def backward(ctx, g_c, g_o):
+        xg, keys, anchors, dsim_g, dsim_c, order = ctx.saved_tensors
+        G, B, C, J = ctx.dims
+        dg = dsim_g * g_c
+        dc = dsim_c * g_o
+        d_xg = dg @ keys
+        d_keys = dg.t() @ xg + dc.t() @ anchors
+        d_anchors = dc @ keys
+        d_x = torch.zeros(G, B, C, dtype=keys.dtype, device=keys.device)
+        d_x.index_add_(0, order[:-1], d_anchors.view(G - 1, B, C))
+        return d_xg, d_x.view(G * B, C), d_keys, None, None, None
+
+
+def contrastive_losses(num_crop, x_global, x, order, x_keys=None, clip_offset=0):
+    """(loss_c, loss_circle) = (global_contrast(...), circle_contrast(...)) through the HIP loss kernel."""
+    keys = x if x_keys is None else x_keys
+    order = torch.as_tensor(order, device=x.device, dtype=torch.long)
+    if keys is x:
+        keys = x.view_as(x)            # distinct autograd input so that d_keys and d_x accumulate separately
+    return _ContrastiveLosses.apply(x_global, x, keys, order, num_crop, clip_offset)

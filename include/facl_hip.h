@@ -154,6 +154,16 @@ int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y,
 int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                           int64_t M, int S, int C, const float* bnc, const float* kk, float* dy, void* stream);
 
+/* ---- contrastive losses on a similarity matrix (utils_my.py:53-116) ----------------------------
+ * sim (R,J) = anchors @ keys^T, R = nA*B rows (row i*B+n: clip n), J = G*Bk columns (column j belongs to
+ * clip j % Bk).  Same-clip columns count as exp(0) (the reference multiplies them by 0); the nA rows of a
+ * clip form ONE shared negative set; nS positive slots per clip, slot s reads its positive from row
+ * (slot_rows ? s : 0)*B+n, column poscol[s*B+n]; CE = mean over B, summed over the slots.
+ *   circle loss: nA = nS = G-1, slot_rows = 1;   global loss: nA = 1, nS = G, slot_rows = 0.
+ * clip_offset = rank*B under data parallelism.  Outputs: loss (1 double), dsim (R,J) = d loss / d sim. */
+int facl_contrast(const float* sim, int R, int J, int B, int Bk, int nA, int nS, int slot_rows,
+                  const int32_t* poscol, int clip_offset, float* dsim, double* loss, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

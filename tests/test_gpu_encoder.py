@@ -193,3 +193,35 @@ def test_step_vs_fp64_oracle_headline_shapes_small_batch():
     e_mine, e_t32 = abs(loss.item() - l64) / abs(l64), abs(l32 - l64) / abs(l64)
     print(f"loss: mine {loss.item():.6f} fp64 {l64:.6f}  rel {e_mine:.2e}   torch-fp32 rel {e_t32:.2e}")
     assert e_mine < TOL
+
+
+@pytest.mark.parametrize("G,B,C,world", [(6, 5, 32, 1), (24, 32, 512, 1), (4, 3, 16, 2)])
+def test_fused_loss_kernel_vs_closed_form_fp64(G, B, C, world):
+    """facl_contrast (value + d/dsim) vs the device-agnostic closed form of utils_my.global/circle_contrast in fp64,
+    including the data-parallel form (keys from a larger global batch, clip_offset)."""
+    from facl_amd.utils_my import circle_contrast, contrastive_losses, global_contrast
+    torch.manual_seed(G * B)
+    Bk = B * world
+    off = B * (world - 1)
+    keys0 = (torch.randn(G, Bk, C, dtype=torch.float64) * 0.3).to(DEV)
+    x0 = keys0[:, off:off + B].reshape(G * B, C).clone()
+    xg0 = (torch.randn(B, C, dtype=torch.float64) * 0.3).to(DEV)
+    order = np.random.RandomState(0).permutation(G)
+
+    def keys_of(x, dtype):
+        # the keys are the all-gathered embeddings: this rank's rows ARE x (gradient flows back into x)
+        k = keys0.to(dtype).clone()
+        k[:, off:off + B] = x.view(G, B, C)
+        return k.reshape(G * Bk, C)
+
+    x64, xg64 = x0.clone().requires_grad_(True), xg0.clone().requires_grad_(True)
+    k64 = keys_of(x64, torch.float64)
+    ref = global_contrast(G, xg64, x64, None, x_keys=k64, clip_offset=off) + \
+        circle_contrast(G, x64, B, order=order, x_keys=k64, clip_offset=off)
+    gr = torch.autograd.grad(ref, (xg64, x64))
+    x32, xg32 = x0.float().requires_grad_(True), xg0.float().requires_grad_(True)
+    lc, lo = contrastive_losses(G, xg32, x32, order, x_keys=keys_of(x32, torch.float32), clip_offset=off)
+    gm = torch.autograd.grad(lc + lo, (xg32, x32))
+    assert abs(float(lc + lo) - float(ref)) <= 2e-6 * abs(float(ref))
+    for a, b, nm in zip(gm, gr, ("xg", "x")):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, nm

@@ -83,9 +83,18 @@ def dominant_kernel_roofline(a, dev):
     ms = e0.elapsed_time(e1) / iters        # includes the 2-us partial-sum reduce that follows each launch
     flops = 2.0 * 64 * 256 * nunits * 64
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch: PMC counters are collected offline (rocprofv3 --pmc, profiles/pmc_traffic.json) at this
+    # exact shape; reported only when the shape matches, else null.
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pm["shape"] == {"B": a.B, "T": a.T, "N": a.N, "D": a.D}:
+            traffic = pm["k_sa_fwd3"]
+    except Exception:
+        traffic = None
     return {"kernel": "k_sa_fwd3", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
-            "ms_per_launch": round(ms, 4)}
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+            "ms_per_launch": round(ms, 4), "algorithmic_flops_per_launch": flops}
 
 
 def cpu_baseline(a):

@@ -38,7 +38,11 @@ class _Affine(nn.Module):
 
 
 class _BatchNormState(nn.Module):
-    """gamma/beta + running buffers under nn.BatchNorm's names."""
+    """gamma/beta + running buffers under nn.BatchNorm's names.
+
+    ``num_batches_tracked`` is counted on the HOST (``steps``) and written into the buffer only when a
+    state_dict is taken: incrementing a device int64 costs one kernel launch per BN layer per call (8 per
+    training step) for a number nothing on the device ever reads."""
 
     def __init__(self, C):
         super().__init__()
@@ -47,6 +51,21 @@ class _BatchNormState(nn.Module):
         self.register_buffer("running_mean", torch.zeros(C))
         self.register_buffer("running_var", torch.ones(C))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.steps = 0
+        self.register_state_dict_pre_hook(_BatchNormState._sync_counter)
+
+    @staticmethod
+    def _sync_counter(module, prefix, keep_vars):
+        module.num_batches_tracked.fill_(module.steps)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        key = prefix + "num_batches_tracked"
+        if key in state_dict:
+            self.steps = int(state_dict[key])
+
+    def count_batch(self):
+        self.steps += 1
 
 
 class _Slots(nn.Module):
@@ -136,7 +155,7 @@ class PointNet_Plus(nn.Module):
         pooled = sa_mlp.SAMLPFunction.apply(x_rows, state, *params)           # (M*S,256)   net3DV_1 (:218)
         if training:
             for i in (1, 4, 7):
-                self.net3DV_1[i].num_batches_tracked += 1
+                self.net3DV_1[i].count_batch()
 
         h = torch.cat((centers, pooled), 1)                                    # :219
         for li in (0, 3):                                                      # net3DV_3 (:220)

@@ -145,3 +145,133 @@ extern "C" int facl_sa_l1tab(const float* W1, const float* b1, int D, const floa
     hipLaunchKernelGGL(k_l1tab, dim3(1), dim3(64), 0, (hipStream_t)stream, W1, b1, D, scale, shift, l1tab);
     return facl_launch_status();
 }
+
+// ================================================================================================
+// Closed-form assembly between the backward passes of the SA point-MLP (csrc/sa_bwd.hip), fp64.
+namespace {
+
+// G3 = W3^T diag(g) W3,  h3' = W3^T (-(1/P) s3 dbeta3 + g (b3 - mean3)),  g = -(1/P) s3 dgamma3 invstd3
+__global__ __launch_bounds__(256) void k_sa_bwd_consts3(const double* __restrict__ sums0, const float* __restrict__ bnc3,
+                                                        const float* __restrict__ W3, const float* __restrict__ b3,
+                                                        double P, float* __restrict__ G3, float* __restrict__ h3) {
+    __shared__ double g[256], hc[256];
+    const int c = threadIdx.x;
+    {
+        const double mean = bnc3[c], inv = bnc3[256 + c], sc = bnc3[512 + c];
+        const double gg = -(sc * sums0[2 * c + 1] * inv) / P;
+        g[c] = gg;
+        hc[c] = -(sc * sums0[2 * c]) / P + gg * ((double)b3[c] - mean);
+    }
+    __syncthreads();
+    const int o = blockIdx.x * 256 + threadIdx.x;       // 0..4095: G3[k][j]; 4096..4159: h3[j]
+    if (o < 4096) {
+        const int k = o >> 6, j = o & 63;
+        double s = 0;
+        for (int cc = 0; cc < 256; ++cc) s += g[cc] * (double)W3[cc * 64 + k] * (double)W3[cc * 64 + j];
+        G3[o] = (float)s;
+    } else if (o < 4160) {
+        const int j = o - 4096;
+        double s = 0;
+        for (int cc = 0; cc < 256; ++cc) s += hc[cc] * (double)W3[cc * 64 + j];
+        h3[j] = (float)s;
+    }
+}
+
+// bw2 (4,64): dy2 = scale2*dz2 + A + B*(y2 - mean2)
+__global__ void k_sa_bwd_consts2(const double* __restrict__ sums1, const float* __restrict__ bnc2, double P,
+                                 float* __restrict__ bw2) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    const double inv = bnc2[64 + c], sc = bnc2[128 + c];
+    bw2[c] = (float)sc;
+    bw2[64 + c] = (float)(-sc * sums1[2 * c] / P);
+    bw2[128 + c] = (float)(-sc * inv * sums1[2 * c + 1] / P);
+    bw2[192 + c] = bnc2[c];
+}
+
+// parameter gradients of layers 3, 2 and 1 from the reduced partial sums
+__global__ __launch_bounds__(256) void k_sa_bwd_final(
+    const double* __restrict__ out3, const double* __restrict__ sums0_g, const double* __restrict__ sums0_l,
+    const float* __restrict__ bnc3, const float* __restrict__ W3, const float* __restrict__ b3,
+    const double* __restrict__ out2, const double* __restrict__ sums1_l, const double* __restrict__ R1_g,
+    const double* __restrict__ mom_l, const float* __restrict__ bnc1, const float* __restrict__ W1,
+    const float* __restrict__ b1, int D, double P, float* __restrict__ dW3, float* __restrict__ dg3,
+    float* __restrict__ dbe3, float* __restrict__ dW2, float* __restrict__ dg2, float* __restrict__ dbe2,
+    float* __restrict__ dW1, float* __restrict__ dg1, float* __restrict__ dbe1) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const double* sparse3 = out3;
+    const double* gram2 = out3 + 256 * 64;
+    const double* s2 = out3 + 256 * 64 + 64 * 64;
+    if (o < 16384) {                                            // dW3[c][k]
+        const int c = o >> 6, k = o & 63;
+        const double mean = bnc3[c], inv = bnc3[256 + c], sc = bnc3[512 + c];
+        double wg = 0;
+        for (int j = 0; j < 64; ++j) wg += (double)W3[c * 64 + j] * gram2[j * 64 + k];
+        const double yhat_a2 = inv * (wg + ((double)b3[c] - mean) * s2[k]);       // sum_p yhat3[p,c] a2[p,k]
+        dW3[o] = (float)(sparse3[o] - (sc / P) * (sums0_g[2 * c] * s2[k] + sums0_g[2 * c + 1] * yhat_a2));
+        return;
+    }
+    int r = o - 16384;
+    if (r < 256) { dbe3[r] = (float)sums0_l[2 * r]; dg3[r] = (float)sums0_l[2 * r + 1]; return; }
+    r -= 256;
+    if (r < 4096) { dW2[r] = (float)out2[r]; return; }
+    r -= 4096;
+    if (r < 64) { dbe2[r] = (float)sums1_l[2 * r]; dg2[r] = (float)sums1_l[2 * r + 1]; return; }
+    r -= 64;
+    if (r < 64) {                                               // layer 1, channel c = r
+        const int c = r;
+        const double* R1_l = out2 + 4096;                       // (8,64): rows x_d (d<D), then sum dz1
+        const double mean = bnc1[c], inv = bnc1[64 + c], sc = bnc1[128 + c];
+        const double bmm = (double)b1[c] - mean;
+        double wr_l = 0, wr_g = 0;
+        for (int d = 0; d < D; ++d) {
+            wr_l += (double)W1[c * D + d] * R1_l[d * 64 + c];
+            wr_g += (double)W1[c * D + d] * R1_g[d * 64 + c];
+        }
+        const double dbe_l = R1_l[D * 64 + c], dbe_g = R1_g[D * 64 + c];
+        const double dg_l = inv * (wr_l + bmm * dbe_l), dg_g = inv * (wr_g + bmm * dbe_g);
+        dbe1[c] = (float)dbe_l;
+        dg1[c] = (float)dg_l;
+        const double* sx = mom_l;
+        const double* X2 = mom_l + D;
+        for (int d = 0; d < D; ++d) {
+            double wx = 0;
+            for (int j = 0; j < D; ++j) wx += (double)W1[c * D + j] * X2[j * D + d];
+            const double yhat_x = inv * (wx + bmm * sx[d]);                           // sum_p yhat1[p,c] x[p,d]
+            dW1[c * D + d] = (float)(sc * (R1_l[d * 64 + c] - (dbe_g / P) * sx[d] - (dg_g / P) * yhat_x));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int facl_sa_bwd_consts3(const double* sums0, const float* bnc3, const float* W3, const float* b3, double P,
+                                   float* G3, float* h3, void* stream) {
+    if (!sums0 || !bnc3 || !W3 || !b3 || !G3 || !h3) return FACL_E_NULL;
+    if (P < 1) return FACL_E_SHAPE;
+    hipLaunchKernelGGL(k_sa_bwd_consts3, dim3(17), dim3(256), 0, (hipStream_t)stream, sums0, bnc3, W3, b3, P, G3, h3);
+    return facl_launch_status();
+}
+
+extern "C" int facl_sa_bwd_consts2(const double* sums1, const float* bnc2, double P, float* bw2, void* stream) {
+    if (!sums1 || !bnc2 || !bw2) return FACL_E_NULL;
+    if (P < 1) return FACL_E_SHAPE;
+    hipLaunchKernelGGL(k_sa_bwd_consts2, dim3(1), dim3(64), 0, (hipStream_t)stream, sums1, bnc2, P, bw2);
+    return facl_launch_status();
+}
+
+extern "C" int facl_sa_bwd_final(const double* out3, const double* sums0_g, const double* sums0_l, const float* bnc3,
+                                 const float* W3, const float* b3, const double* out2, const double* sums1_l,
+                                 const double* R1_g, const double* mom_l, const float* bnc1, const float* W1,
+                                 const float* b1, int D, double P, float* dW3, float* dg3, float* dbe3, float* dW2,
+                                 float* dg2, float* dbe2, float* dW1, float* dg1, float* dbe1, void* stream) {
+    if (!out3 || !sums0_g || !sums0_l || !bnc3 || !W3 || !b3 || !out2 || !sums1_l || !R1_g || !mom_l || !bnc1 || !W1 ||
+        !b1 || !dW3 || !dg3 || !dbe3 || !dW2 || !dg2 || !dbe2 || !dW1 || !dg1 || !dbe1)
+        return FACL_E_NULL;
+    if ((D != 3 && D != 4) || P < 1) return FACL_E_SHAPE;
+    const int total = 16384 + 256 + 4096 + 64 + 64;
+    hipLaunchKernelGGL(k_sa_bwd_final, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, out3, sums0_g,
+                       sums0_l, bnc3, W3, b3, out2, sums1_l, R1_g, mom_l, bnc1, W1, b1, D, P, dW3, dg3, dbe3, dW2, dg2,
+                       dbe2, dW1, dg1, dbe1);
+    return facl_launch_status();
+}

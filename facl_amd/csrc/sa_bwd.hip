@@ -19,6 +19,7 @@
 //                  R1 += [x|1]^T dz1   (everything layer 1 needs: dW1, dgamma1, dbeta1 follow in closed form)
 // Roofline: MFMA fp32 for bwd1/bwd2/bwd_w3 (128..320 MFMA 32x32x2 per 64 positions), HBM for bwd0.
 #include "common.h"
+#include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
 
@@ -89,14 +90,25 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { pb[a][r] = 0.f; pg[a][r] = 0.f; }
 
+    // register double buffer (see k_sa_bwd_w3): next unit's y2 tile, coef and arg are in flight during this unit
+    float4 yn[16], cfn;
+    uchar4 arn;
+    auto issue_loads = [&](int u) {
+        const float* tl = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tl + (i * 64 + lane) * 4);
+        cfn = *reinterpret_cast<const float4*>(coef + (size_t)u * 256 + 4 * lane);
+        arn = *reinterpret_cast<const uchar4*>(arg + (size_t)u * 256 + 4 * lane);
+    };
+    if (wave_g < nunits) issue_loads(wave_g);
     for (int u = wave_g; u < nunits; u += nwaves) {
         asm volatile("" ::: "memory");
         // ---- sparse rows: srow[arg[c]][j] += coef[c] * W3[c][j]   (lane = channel j)
         // The target row is WAVE-UNIFORM, so the 64 row accumulators live in registers and are addressed
         // with GPR indexing (s_set_gpr_idx): no LDS atomics (ds_add_f32 measured ~700 cycles per
         // wave-instruction on gfx950: 3.6 of this kernel's 4.2 ms), no memory traffic at all.
-        const float4 cf4 = *reinterpret_cast<const float4*>(coef + (size_t)u * 256 + 4 * lane);
-        const uchar4 ar4 = *reinterpret_cast<const uchar4*>(arg + (size_t)u * 256 + 4 * lane);
+        const float4 cf4 = cfn;
+        const uchar4 ar4 = arn;
         const float cfv[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
         const int arv[4] = {ar4.x, ar4.y, ar4.z, ar4.w};
         f32x32 srow0, srow1;
@@ -123,7 +135,6 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
         for (int t = 0; t < 32; ++t) { T[t * TP + lane] = srow0[t]; T[(32 + t) * TP + lane] = srow1[t]; }
         WAVE_LDS_FENCE();      // other lanes read T below
         // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j]
-        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
         float yv[2][2][16];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -131,9 +142,10 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 y = *reinterpret_cast<const float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4);
+                    const float4 y = yn[(ct * 2 + rt) * 4 + r4];
                     yv[ct][rt][4 * r4] = y.x; yv[ct][rt][4 * r4 + 1] = y.y; yv[ct][rt][4 * r4 + 2] = y.z; yv[ct][rt][4 * r4 + 3] = y.w;
                 }
+        if (u + nwaves < nunits) issue_loads(u + nwaves);
         f32x16 acc[2][2];
 #pragma unroll
         for (int ro = 0; ro < 2; ++ro)
@@ -205,74 +217,136 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// bwd_w3: one workgroup per unit at a time.  Output row per workgroup:
-//   [ sparse dW3 (256 x 64) | Gram sum a2^T a2 (64 x 64) | sum a2 (64) ]  = 20544 doubles
+// bwd_w3: one wave per unit (no workgroup barriers in the loop).  Per unit: a2 -> padded LDS tile;
+//   Gram sum_p a2^T a2 on MFMA (3 of the 4 symmetric 32x32 tiles), sum_p a2, and the sparse part of dW3:
+//   lane owns channels c = lane + 64e and adds coef[c] * a2[arg[c]][:] (one LDS row, 16 b128 reads) into 64
+//   register accumulators per channel.  Output row per WORKGROUP (the 4 waves are combined through LDS):
+//   [ sparse dW3 (256 x 64) | Gram (64 x 64) | sum a2 (64) ]  = 20544 doubles
 constexpr int W3_V = 256 * 64 + 64 * 64 + 64;
 
 __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f, int nunits,
                                                    const float* __restrict__ bnc2, const float* __restrict__ coef,
-                                                   const unsigned char* __restrict__ arg, double* __restrict__ part) {
-    __shared__ float T[64 * TQ];
-    __shared__ float4 tab[32];       // scale2, shift2
+                                                   const unsigned char* __restrict__ arg, double* __restrict__ part, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    float4* tab = lds4;                                         // scale2, shift2: 2 x 16 float4
+    float* comb = reinterpret_cast<float*>(lds4 + 32);          // [256][65] sparse dW3 combine (padded rows)
+    float* gcomb = comb + 256 * 65;                             // [64][64] Gram combine
+    float* scomb = gcomb + 64 * 64;                             // [64] sum a2
+    float* T = scomb + 64 + (threadIdx.x >> 6) * (64 * TP);     // per-wave a2 tile; (256*65+4096+64)*4 B is 16-B aligned
     if (threadIdx.x < 32) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2 + 128)[threadIdx.x];
     __syncthreads();
-    const float* sc2 = reinterpret_cast<const float*>(tab);
-    const float* sh2 = sc2 + 64;
+    const float4* sc2 = tab; const float4* sh2 = tab + 16;
     const int lane = lane_id(), h = lane >> 5, q = lane & 31, wave = threadIdx.x >> 6;
-    const int c = threadIdx.x;                         // sparse part: this thread's output channel
-    float accs[64];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) accs[k] = 0.f;
-    f32x16 gram;                                       // Gram tile (rt = wave>>1, ct = wave&1)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gram[r] = 0.f;
-    const int grt = wave >> 1, gct = wave & 1;
-    float s2 = 0.f;                                    // waves 0,1: sum_p a2[p][32*wave + q] over this lane's positions
+    const int wave_g = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
 
-    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
-        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
-        __syncthreads();                               // previous unit's readers are done with T
-        // each wave converts one (ct, rt) quarter of the tile: element (p = 32ct+q, c = 32rt + 8r4 + 4h + e)
-        {
-            const int ct = wave >> 1, rt = wave & 1;
+    float accs[4][64];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 y = *reinterpret_cast<const float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4);
-                const int c0 = 32 * rt + 8 * r4 + 4 * h;
-                float* dst = &T[(32 * ct + q) * TQ + c0];
-                dst[0] = fmaxf(fmaf(sc2[c0], y.x, sh2[c0]), 0.f);
-                dst[1] = fmaxf(fmaf(sc2[c0 + 1], y.y, sh2[c0 + 1]), 0.f);
-                dst[2] = fmaxf(fmaf(sc2[c0 + 2], y.z, sh2[c0 + 2]), 0.f);
-                dst[3] = fmaxf(fmaf(sc2[c0 + 3], y.w, sh2[c0 + 3]), 0.f);
-            }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 64; ++k) accs[e][k] = 0.f;
+    f32x16 g00, g01, g11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { g00[r] = 0.f; g01[r] = 0.f; g11[r] = 0.f; }
+    float s2a = 0.f, s2b = 0.f;
+
+    // register double buffer: the NEXT unit's tile (+ its coef/arg) is requested before this unit's compute, so
+    // the HBM latency is covered by the MFMA / LDS work instead of being exposed once per unit (1 wave per SIMD)
+    float4 yn[16];
+    float cfn[4];
+    int psn[4];
+    auto issue_loads = [&](int u) {
+        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cfn[e] = coef[(size_t)u * 256 + 64 * e + lane];
+            psn[e] = arg[(size_t)u * 256 + 64 * e + lane];
         }
-        const float cf = coef[(size_t)u * 256 + c];
-        const int ps = arg[(size_t)u * 256 + c];
-        __syncthreads();
-        // Gram tile: G[i][j] += sum_p a2[p][32grt+i] a2[p][32gct+j];  A/B lane (h,q): a2[p = 32h+s][32t+q]
+    };
+    if (wave_g < nunits) issue_loads(wave_g);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 y = yn[(ct * 2 + rt) * 4 + r4];
+                    const float4 sc = sc2[8 * rt + 2 * r4 + h], sh = sh2[8 * rt + 2 * r4 + h];
+                    float4 a;
+                    a.x = fmaxf(fmaf(sc.x, y.x, sh.x), 0.f); a.y = fmaxf(fmaf(sc.y, y.y, sh.y), 0.f);
+                    a.z = fmaxf(fmaf(sc.z, y.z, sh.z), 0.f); a.w = fmaxf(fmaf(sc.w, y.w, sh.w), 0.f);
+                    *reinterpret_cast<float4*>(&T[(32 * ct + q) * TP + 32 * rt + 8 * r4 + 4 * h]) = a;
+                }
+        float cfv[4];
+        int psv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cfv[e] = cfn[e]; psv[e] = psn[e]; }
+        if (u + nwaves < nunits) issue_loads(u + nwaves);
+        WAVE_LDS_FENCE();
+        // Gram: G[i][j] += sum_p a2[p][i] a2[p][j]; operands (lane = channel, k = position 32h+s)
+        if (!(dbg & 1))
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const float av = T[(32 * h + s) * TQ + 32 * grt + q];
-            const float bv = T[(32 * h + s) * TQ + 32 * gct + q];
-            gram = MFMA32(av, bv, gram);
-            if (wave < 2) s2 += bv;                    // waves 0,1 have gct = wave: column 32*wave+q
+            const float a0 = T[(32 * h + s) * TP + q], a1 = T[(32 * h + s) * TP + 32 + q];
+            g00 = MFMA32(a0, a0, g00);
+            g01 = MFMA32(a0, a1, g01);
+            g11 = MFMA32(a1, a1, g11);
+            s2a += a0; s2b += a1;
         }
-        // sparse part: dW3[c][:] += coef * a2[arg][:]
-        if (cf != 0.f) {
+        // sparse part of dW3
+        if (!(dbg & 2))
 #pragma unroll
-            for (int k = 0; k < 64; ++k) accs[k] = fmaf(cf, T[ps * TQ + k], accs[k]);
+        for (int e = 0; e < 4; ++e) {
+            const float4* row = reinterpret_cast<const float4*>(&T[psv[e] * TP]);
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const float4 v = row[k4];
+                accs[e][4 * k4 + 0] = fmaf(cfv[e], v.x, accs[e][4 * k4 + 0]);
+                accs[e][4 * k4 + 1] = fmaf(cfv[e], v.y, accs[e][4 * k4 + 1]);
+                accs[e][4 * k4 + 2] = fmaf(cfv[e], v.z, accs[e][4 * k4 + 2]);
+                accs[e][4 * k4 + 3] = fmaf(cfv[e], v.w, accs[e][4 * k4 + 3]);
+            }
         }
+        WAVE_LDS_FENCE();      // next unit overwrites T
+    }
+    // combine the 4 waves through LDS (wave w adds in phase w), then one fp64 row per workgroup
+    const float s2ta = s2a + __shfl_xor(s2a, 32, 64), s2tb = s2b + __shfl_xor(s2b, 32, 64);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    float* d = &comb[(64 * e + lane) * 65 + k];
+                    *d = (w == 0 ? 0.f : *d) + accs[e][k];
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rowmap(r, h);
+                float* d00 = &gcomb[i * 64 + q];
+                float* d01 = &gcomb[i * 64 + 32 + q];
+                float* d11 = &gcomb[(32 + i) * 64 + 32 + q];
+                *d00 = (w == 0 ? 0.f : *d00) + g00[r];
+                *d01 = (w == 0 ? 0.f : *d01) + g01[r];
+                *d11 = (w == 0 ? 0.f : *d11) + g11[r];
+            }
+            if (h == 0) {
+                scomb[q] = (w == 0 ? 0.f : scomb[q]) + s2ta;
+                scomb[32 + q] = (w == 0 ? 0.f : scomb[32 + q]) + s2tb;
+            }
+        }
+        __syncthreads();
     }
     double* row = part + (size_t)blockIdx.x * W3_V;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) row[(size_t)c * 64 + k] = (double)accs[k];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        row[256 * 64 + (32 * grt + rowmap(r, h)) * 64 + 32 * gct + q] = (double)gram[r];
-    if (wave < 2) {
-        const float tot = s2 + __shfl_xor(s2, 32, 64);
-        if (h == 0) row[256 * 64 + 64 * 64 + 32 * wave + q] = (double)tot;
+    for (int i = threadIdx.x; i < 256 * 64; i += 256) row[i] = (double)comb[(i >> 6) * 65 + (i & 63)];
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int a = i >> 6, b = i & 63;
+        row[256 * 64 + i] = (double)((a >= 32 && b < 32) ? gcomb[b * 64 + a] : gcomb[i]);     // lower-left = upper-right^T
     }
+    if (threadIdx.x < 64) row[256 * 64 + 64 * 64 + threadIdx.x] = (double)scomb[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,8 +550,16 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
     if (!y2f || !bnc2 || !coef || !arg || !out || !ws) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = (int)(nunits < 512 ? nunits : 512);
-    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), 0, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws);
+    const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
+    const size_t lds = 32 * sizeof(float4) + (256 * 65 + 64 * 64 + 64 + 4 * 64 * TP) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_sa_bwd_w3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    static int dbg = getenv("FACL_DBG") ? atoi(getenv("FACL_DBG")) : 0;
+    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, dbg);
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, grid, W3_V, out, st);

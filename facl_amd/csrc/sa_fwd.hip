@@ -83,9 +83,8 @@ __global__ __launch_bounds__(256) void k_sa_fwd2(const float* __restrict__ x, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ps[rt][r] = 0.f; pq[rt][r] = 0.f; }
 
-    for (int u = wave_g; u < nunits; u += nwaves) {
-        asm volatile("" ::: "memory");       // LDS tables are re-read per unit instead of living in registers
-        float xv[2][4];
+    // software prefetch: with one wave per SIMD the HBM latency of the next unit's input is otherwise exposed
+    auto load_x = [&](int u, float (&xv)[2][4]) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const size_t p = (size_t)u * 64 + 32 * ct + q;
@@ -96,6 +95,17 @@ __global__ __launch_bounds__(256) void k_sa_fwd2(const float* __restrict__ x, in
                 xv[ct][0] = x[p * 3]; xv[ct][1] = x[p * 3 + 1]; xv[ct][2] = x[p * 3 + 2]; xv[ct][3] = 0.f;
             }
         }
+    };
+    float xn[2][4];
+    if (wave_g < nunits) load_x(wave_g, xn);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        asm volatile("" ::: "memory");       // LDS tables are re-read per unit instead of living in registers
+        float xv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[ct][i] = xn[ct][i];
+        if (u + nwaves < nunits) load_x(u + nwaves, xn);
         // layer 1 on the VALU: this lane's two positions x the 32 channels of its half
         float a1[2][32];
 #pragma unroll
@@ -213,8 +223,15 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) stat[i * 64 + lane] = make_double2(0.0, 0.0);
 
-    for (int u = wave_g; u < nunits; u += nwaves) {
+    // register double buffer: the next unit's y2 tile is requested before this unit's 512 MFMAs
+    float4 yn[16];
+    auto issue_loads = [&](int u) {
         const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
+    };
+    if (wave_g < nunits) issue_loads(wave_g);
+    for (int u = wave_g; u < nunits; u += nwaves) {
         float a2[2][2][16];                   // [pt][rt][r] = a2[p = 32pt+q][k = 32rt+rowmap(r,h)]
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -222,13 +239,14 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 y = *reinterpret_cast<const float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4);
+                    const float4 y = yn[(ct * 2 + rt) * 4 + r4];
                     const float4 sc = sc2s[8 * rt + 2 * r4 + h], sh = sh2s[8 * rt + 2 * r4 + h];
                     a2[ct][rt][4 * r4 + 0] = fmaxf(fmaf(sc.x, y.x, sh.x), 0.f);
                     a2[ct][rt][4 * r4 + 1] = fmaxf(fmaf(sc.y, y.y, sh.y), 0.f);
                     a2[ct][rt][4 * r4 + 2] = fmaxf(fmaf(sc.z, y.z, sh.z), 0.f);
                     a2[ct][rt][4 * r4 + 3] = fmaxf(fmaf(sc.w, y.w, sh.w), 0.f);
                 }
+        if (u + nwaves < nunits) issue_loads(u + nwaves);
 #pragma unroll 1
         for (int ct3 = 0; ct3 < 8; ++ct3) {
             const float bias = b3s[32 * ct3 + q];

@@ -40,6 +40,7 @@ def make_bn_reduce_fn(group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return t
 
+    reduce_fn.world_size = dist.get_world_size(group)        # equal shards: global counts = local * world_size
     return reduce_fn
 
 

@@ -66,13 +66,12 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
     W3 = p["W3"].reshape(256, 64)
     ctx = {}
     if training:
-        mom = torch.empty(D + D * D + 1, **f64)
-        mom[-1] = count
+        mom = torch.empty(D + D * D, **f64)
         _lib.check(lib.facl_sa_x_moments(_lib.ptr(x_rows), P, D, _lib.ptr(mom), _lib.ptr(ws), st), "facl_sa_x_moments")
-        ctx["mom_local"] = mom.clone()
+        ctx["mom_local"] = mom
         if reduce_fn is not None:
-            reduce_fn(mom)
-            count = float(mom[-1].item())
+            mom = reduce_fn(mom.clone())
+            count = float(P) * reduce_fn.world_size          # every rank holds the same number of positions
         sums1 = torch.empty((64, 2), **f64)
         _lib.check(lib.facl_bn1_sums_from_moments(_lib.ptr(mom), count, D, _lib.ptr(W1), _lib.ptr(p["b1"]),
                                                   _lib.ptr(sums1), st), "facl_bn1_sums_from_moments")
@@ -122,84 +121,69 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
 def sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     """Gradients of the 12 parameters of net3DV_1 given dL/dpooled (P/64,256).
 
-    Heavy passes are HIP (csrc/sa_bwd.hip); the O(10^4)-element closed-form assembly between
-    them is fp64 tensor algebra on the stream.  ``reduce_fn`` all-reduces the BN-backward sums
-    (SyncBN); parameter gradients stay LOCAL sums (DDP averages them)."""
+    Four heavy passes (csrc/sa_bwd.hip) with three fp64 closed-form assembly kernels between them
+    (csrc/finalize.hip).  ``reduce_fn`` all-reduces the BN-backward sums (SyncBN); parameter gradients stay
+    LOCAL sums (the data-parallel wrapper averages them)."""
     lib = _lib.load_library()
     dev = x_rows.device
     st = _lib.stream()
     ws = _Workspace.get(dev)
     f64 = dict(dtype=torch.float64, device=dev)
-    nunits, D, P = ctx["nunits"], ctx["D"], ctx["count"]
+    f32 = dict(dtype=torch.float32, device=dev)
+    nunits, D, P = ctx["nunits"], ctx["D"], float(ctx["count"])
     bnc1, bnc2, bnc3 = ctx["bnc1"], ctx["bnc2"], ctx["bnc3"]
-    W1 = p["W1"].reshape(64, D).double()
+    W1 = p["W1"].reshape(64, D)
     W2 = p["W2"].reshape(64, 64)
     W3 = p["W3"].reshape(256, 64)
-    W3d = W3.double()
     dpooled = dpooled.contiguous()
+    ptr = _lib.ptr
 
     # ---- pass 0: sparse values + (dbeta3, dgamma3)
-    coef = torch.empty((nunits, 256), dtype=torch.float32, device=dev)
+    coef = torch.empty((nunits, 256), **f32)
     sums0 = torch.empty((256, 2), **f64)
-    _lib.check(lib.facl_sa_bwd0(_lib.ptr(dpooled), _lib.ptr(ctx["ymax"]), nunits, _lib.ptr(bnc3), _lib.ptr(coef),
-                                _lib.ptr(sums0), _lib.ptr(ws), st), "facl_sa_bwd0")
-    dbe3_l, dg3_l = sums0[:, 0].clone(), sums0[:, 1].clone()
+    _lib.check(lib.facl_sa_bwd0(ptr(dpooled), ptr(ctx["ymax"]), nunits, ptr(bnc3), ptr(coef), ptr(sums0), ptr(ws), st),
+               "facl_sa_bwd0")
+    sums0_l = sums0
     if reduce_fn is not None:
-        reduce_fn(sums0)
-    mean3, inv3, sc3 = bnc3[0].double(), bnc3[1].double(), bnc3[2].double()
-    g = -(sc3 * sums0[:, 1] * inv3) / P
-    G3 = (W3d.t() @ (g[:, None] * W3d))
-    h3 = W3d.t() @ (-(sc3 * sums0[:, 0]) / P + g * (p["b3"].double() - mean3))
-    G3f, h3f = G3.float().contiguous(), h3.float().contiguous()
+        sums0 = reduce_fn(sums0.clone())
+    G3, h3 = torch.empty((64, 64), **f32), torch.empty(64, **f32)
+    _lib.check(lib.facl_sa_bwd_consts3(ptr(sums0), ptr(bnc3), ptr(W3), ptr(p["b3"]), P, ptr(G3), ptr(h3), st),
+               "facl_sa_bwd_consts3")
 
     # ---- pass 1: dz2 + (dbeta2, dgamma2)
     dz2f = torch.empty_like(ctx["y2f"])
     sums1 = torch.empty((64, 2), **f64)
-    _lib.check(lib.facl_sa_bwd1(_lib.ptr(ctx["y2f"]), nunits, _lib.ptr(bnc2), _lib.ptr(G3f), _lib.ptr(h3f),
-                                _lib.ptr(W3), _lib.ptr(coef), _lib.ptr(ctx["arg"]), _lib.ptr(dz2f), _lib.ptr(sums1),
-                                _lib.ptr(ws), st), "facl_sa_bwd1")
-    dbe2_l, dg2_l = sums1[:, 0].clone(), sums1[:, 1].clone()
+    _lib.check(lib.facl_sa_bwd1(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(G3), ptr(h3), ptr(W3), ptr(coef), ptr(ctx["arg"]),
+                                ptr(dz2f), ptr(sums1), ptr(ws), st), "facl_sa_bwd1")
+    sums1_l = sums1
     if reduce_fn is not None:
-        reduce_fn(sums1)
+        sums1 = reduce_fn(sums1.clone())
 
-    # ---- layer-3 weight gradient: sparse gather + Gram closed form
+    # ---- layer-3 weight gradient ingredients: sparse gather, Gram, sum a2
     out3 = torch.empty(256 * 64 + 64 * 64 + 64, **f64)
-    _lib.check(lib.facl_sa_bwd_w3(_lib.ptr(ctx["y2f"]), nunits, _lib.ptr(bnc2), _lib.ptr(coef), _lib.ptr(ctx["arg"]),
-                                  _lib.ptr(out3), _lib.ptr(ws), st), "facl_sa_bwd_w3")
-    sparse3 = out3[:256 * 64].view(256, 64)
-    gram2 = out3[256 * 64:256 * 64 + 4096].view(64, 64)
-    s2 = out3[256 * 64 + 4096:]
-    yhat_a2 = inv3[:, None] * (W3d @ gram2 + (p["b3"].double() - mean3)[:, None] * s2[None, :])   # sum_p yhat3 a2
-    dW3 = sparse3 - (sc3 / P)[:, None] * (sums0[:, 0][:, None] * s2[None, :] + sums0[:, 1][:, None] * yhat_a2)
+    _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
+               "facl_sa_bwd_w3")
 
     # ---- pass 2: dy2, da1, dz1, dW2, R1
-    sc2, inv2, mean2 = bnc2[2].double(), bnc2[1].double(), bnc2[0].double()
-    bw2 = torch.stack([sc2, -sc2 * sums1[:, 0] / P, -sc2 * inv2 * sums1[:, 1] / P, mean2]).float().contiguous()
+    bw2 = torch.empty((4, 64), **f32)
+    _lib.check(lib.facl_sa_bwd_consts2(ptr(sums1), ptr(bnc2), P, ptr(bw2), st), "facl_sa_bwd_consts2")
     out2 = torch.empty(64 * 64 + 8 * 64, **f64)
-    _lib.check(lib.facl_sa_bwd2(_lib.ptr(dz2f), _lib.ptr(ctx["y2f"]), _lib.ptr(x_rows), nunits, D, _lib.ptr(bw2),
-                                _lib.ptr(W2), _lib.ptr(ctx["l1tab"]), _lib.ptr(out2), _lib.ptr(ws), st),
-               "facl_sa_bwd2")
-    dW2 = out2[:4096].view(64, 64)
-    R1_l = out2[4096:].view(8, 64)
-    R1 = R1_l.clone()
+    _lib.check(lib.facl_sa_bwd2(ptr(dz2f), ptr(ctx["y2f"]), ptr(x_rows), nunits, D, ptr(bw2), ptr(W2), ptr(ctx["l1tab"]),
+                                ptr(out2), ptr(ws), st), "facl_sa_bwd2")
+    R1_g = out2[4096:]
     if reduce_fn is not None:
-        reduce_fn(R1)
-    mean1, inv1, sc1 = bnc1[0].double(), bnc1[1].double(), bnc1[2].double()
-    b1 = p["b1"].double()
+        R1_g = reduce_fn(R1_g.clone())
 
-    def dgamma1(R):
-        return inv1 * ((W1 * R[:D].t()).sum(1) + (b1 - mean1) * R[D])
-
-    dbe1_g, dg1_g = R1[D], dgamma1(R1)
-    mom = ctx["mom_local"]
-    sx, X2 = mom[:D], mom[D:D + D * D].view(D, D)
-    yhat_x = inv1[:, None] * (W1 @ X2 + (b1 - mean1)[:, None] * sx[None, :])                      # sum_p yhat1 x
-    dW1 = sc1[:, None] * (R1_l[:D].t() - (dbe1_g / P)[:, None] * sx[None, :] - (dg1_g / P)[:, None] * yhat_x)
-
-    z64, z256 = torch.zeros(64, dtype=torch.float32, device=dev), torch.zeros(256, dtype=torch.float32, device=dev)
-    return {"W1": dW1.float().view_as(p["W1"]), "b1": z64, "g1": dgamma1(R1_l).float(), "be1": R1_l[D].float(),
-            "W2": dW2.float().view_as(p["W2"]), "b2": z64.clone(), "g2": dg2_l.float(), "be2": dbe2_l.float(),
-            "W3": dW3.float().view_as(p["W3"]), "b3": z256, "g3": dg3_l.float(), "be3": dbe3_l.float()}
+    g = {"W3": torch.empty_like(p["W3"]), "g3": torch.empty(256, **f32), "be3": torch.empty(256, **f32),
+         "W2": torch.empty_like(p["W2"]), "g2": torch.empty(64, **f32), "be2": torch.empty(64, **f32),
+         "W1": torch.empty_like(p["W1"]), "g1": torch.empty(64, **f32), "be1": torch.empty(64, **f32),
+         # d(bias) of a conv that feeds a train-mode BN is identically zero: None (the parameter is left untouched)
+         "b1": None, "b2": None, "b3": None}
+    _lib.check(lib.facl_sa_bwd_final(ptr(out3), ptr(sums0), ptr(sums0_l), ptr(bnc3), ptr(W3), ptr(p["b3"]), ptr(out2),
+                                     ptr(sums1_l), ptr(R1_g), ptr(ctx["mom_local"]), ptr(bnc1), ptr(W1), ptr(p["b1"]),
+                                     D, P, ptr(g["W3"]), ptr(g["g3"]), ptr(g["be3"]), ptr(g["W2"]), ptr(g["g2"]),
+                                     ptr(g["be2"]), ptr(g["W1"]), ptr(g["g1"]), ptr(g["be1"]), st), "facl_sa_bwd_final")
+    return g
 
 
 _PARAM_ORDER = ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3", "g3", "be3")

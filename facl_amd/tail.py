@@ -27,11 +27,10 @@ def _forward_bn_consts(y, bn, training, reduce_fn, ws):
     sums = _stats(y, ws)
     count = float(R)
     if reduce_fn is not None:
-        packed = torch.cat([sums.reshape(-1), torch.tensor([count], dtype=torch.float64, device=y.device)])
-        reduce_fn(packed)
-        sums, count = packed[:-1].view(C, 2), float(packed[-1].item())
+        reduce_fn(sums)
+        count = count * reduce_fn.world_size                  # equal shards (no host round trip for the count)
     bnc = _bn_finalize(sums, C, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
-    bn.num_batches_tracked += 1
+    bn.count_batch()
     return bnc, count
 
 
@@ -64,16 +63,19 @@ class _LinearBNReLU(torch.autograd.Function):
         sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
         _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws),
                                            _lib.stream()), "facl_rows_bwd_stats")
-        dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()          # parameter gradients stay local
+        sl = sums.float()                                               # parameter gradients stay local sums
+        dbeta, dgamma = sl[:, 0], sl[:, 1]
         if ctx.reduce_fn is not None:
             ctx.reduce_fn(sums)
-        kk = (sums.t() / ctx.count).float().contiguous()               # (2,C): dbeta/P, dgamma/P
+            sl = sums.float()
+        kk = (sl.t() * (1.0 / ctx.count)).contiguous()                  # (2,C): dbeta/P, dgamma/P
         dy = torch.empty_like(y)
         _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                            _lib.stream()), "facl_rows_bwd_apply")
         dW = dy.t() @ h                                                 # library GEMMs
         dh = dy @ W if ctx.needs_input_grad[0] else None
-        return dh, dW, torch.zeros_like(dbeta), dgamma, dbeta, None, None, None
+        # d(bias) is identically zero in front of a train-mode BN: None leaves the parameter untouched
+        return dh, dW, None, dgamma, dbeta, None, None, None
 
 
 class _LinearBNSegmax(torch.autograd.Function):
@@ -113,17 +115,19 @@ class _LinearBNSegmax(torch.autograd.Function):
         _lib.check(lib.facl_segmax_bwd_stats(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
                    "facl_segmax_bwd_stats")
-        dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()
+        sl = sums.float()
+        dbeta, dgamma = sl[:, 0], sl[:, 1]
         if ctx.reduce_fn is not None:
             ctx.reduce_fn(sums)
-        kk = (sums.t() / ctx.count).float().contiguous()
+            sl = sums.float()
+        kk = (sl.t() * (1.0 / ctx.count)).contiguous()
         dy = torch.empty_like(y)
         _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), _lib.stream()),
                    "facl_segmax_bwd_apply")
         dW = dy.t() @ h
         dh = dy @ W
-        return dh, dW, torch.zeros_like(dbeta), dgamma, dbeta, None, None, None, None
+        return dh, dW, None, dgamma, dbeta, None, None, None, None
 
 
 def linear_bn_relu(h, affine, bn, training, reduce_fn=None):

@@ -128,6 +128,20 @@ int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc2, const fl
 int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nunits, int D,
                  const float* bw2, const float* W2, const float* l1tab, double* out, void* ws,
                  void* stream);
+/* fp64 closed-form assembly between those passes (csrc/finalize.hip).  "_g" = after the SyncBN all-reduce,
+ * "_l" = this rank's sums (parameter gradients stay local; the data-parallel wrapper averages them).
+ *   facl_sa_bwd_consts3  sums0 (dbeta3,dgamma3) -> G3 (64,64), h3 (64) for facl_sa_bwd1
+ *   facl_sa_bwd_consts2  sums1 (dbeta2,dgamma2) -> bw2 (4,64) for facl_sa_bwd2
+ *   facl_sa_bwd_final    all partial sums -> dW3,dgamma3,dbeta3, dW2,dgamma2,dbeta2, dW1,dgamma1,dbeta1
+ *                        (R1_g (8,64) = all-reduced tail of facl_sa_bwd2's output, mom_l = local x moments) */
+int facl_sa_bwd_consts3(const double* sums0, const float* bnc3, const float* W3, const float* b3, double P,
+                        float* G3, float* h3, void* stream);
+int facl_sa_bwd_consts2(const double* sums1, const float* bnc2, double P, float* bw2, void* stream);
+int facl_sa_bwd_final(const double* out3, const double* sums0_g, const double* sums0_l, const float* bnc3,
+                      const float* W3, const float* b3, const double* out2, const double* sums1_l,
+                      const double* R1_g, const double* mom_l, const float* bnc1, const float* W1,
+                      const float* b1, int D, double P, float* dW3, float* dg3, float* dbe3, float* dW2,
+                      float* dg2, float* dbe2, float* dW1, float* dg1, float* dbe1, void* stream);
 
 /* ---- encoder tail: row-major (R,C) BatchNorm / ReLU / max-over-S kernels ----------------------
  * net3DV_3 + my_max_pool + netR_FC (cn3d_model_conbag.py:61-88, :199-207).  The dense contractions

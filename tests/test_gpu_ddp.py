@@ -77,7 +77,8 @@ def test_two_ranks_equal_single_process_global_batch():
     gmax = max(float(np.linalg.norm(v.numpy())) for v in grads1.values())
     for k, g1 in grads1.items():
         g1 = g1.numpy()
-        for r in (0, 1):                                          # after the averaged all-reduce both ranks agree
+        for r in (0, 1):
+            assert k in res[r][2], k                                          # after the averaged all-reduce both ranks agree
             g2 = res[r][2][k]
             assert np.linalg.norm(g2 - g1) <= 2e-4 * max(np.linalg.norm(g1), 1e-2 * gmax) + 1e-6, (k, r)
     for k, b1 in bufs1.items():                                   # SyncBN: running statistics of the GLOBAL batch

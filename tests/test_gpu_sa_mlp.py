@@ -115,9 +115,9 @@ def test_sa_backward_vs_oracle_fp64(D, neg):
               "W3": "net3DV_1.6.weight", "b3": "net3DV_1.6.bias", "g3": "net3DV_1.7.weight", "be3": "net3DV_1.7.bias"}
     for k, prm in zip(names, params):
         r64 = g64[keymap[k]].numpy()
-        mine = prm.grad.cpu().numpy().reshape(r64.shape)
+        mine = None if prm.grad is None else prm.grad.cpu().numpy().reshape(r64.shape)
         if k in ("b1", "b2", "b3"):                    # mathematically zero (bias before a train-mode BN)
-            assert np.abs(mine).max() == 0.0
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
             continue
         e_mine = rel_err(mine, r64)
         e_t32 = rel_err(g32[keymap[k]].numpy(), r64)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Per-kernel timing of the SA point-MLP passes at the headline shape (HIP events on the launch stream)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facl_amd import _lib                      # noqa: E402
+from facl_amd.sa_mlp import _Workspace         # noqa: E402
+
+
+def timeit(fn, iters=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--M", type=int, default=768)
+    ap.add_argument("--D", type=int, default=3)
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    lib = _lib.load_library()
+    dev = torch.device("cuda:0")
+    nunits, D = a.M * 64, a.D
+    P = nunits * 64
+    g = torch.Generator(device=dev).manual_seed(0)
+    R = lambda *s: torch.randn(*s, device=dev, generator=g)          # noqa: E731
+    x = R(P, D) * 0.3
+    y2f, dz2f = R(nunits * 4096), torch.empty(nunits * 4096, device=dev)
+    bnc2 = torch.rand(5, 64, device=dev, generator=g) + 0.5
+    bnc3 = torch.rand(5, 256, device=dev, generator=g) + 0.5
+    W1, b1 = R(64, D) * 0.3, R(64) * 0.1
+    W2, b2, W3, b3 = R(64, 64) * 0.1, R(64) * 0.1, R(256, 64) * 0.1, R(256) * 0.1
+    l1tab = torch.empty(64, 8, device=dev)
+    _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(b1), D, None, None, _lib.ptr(l1tab), _lib.stream()), "l1tab")
+    sgn = torch.ones(256, device=dev)
+    ymax, arg = torch.empty(nunits, 256, device=dev), torch.randint(0, 64, (nunits, 256), dtype=torch.uint8, device=dev)
+    coef = R(nunits, 256)
+    G3, h3 = R(64, 64) * 0.01, R(64) * 0.01
+    bw2 = torch.rand(4, 64, device=dev, generator=g)
+    ws = _Workspace.get(dev)
+    s64 = torch.empty(64, 2, dtype=torch.float64, device=dev)
+    s256 = torch.empty(256, 2, dtype=torch.float64, device=dev)
+    o3 = torch.empty(20544, dtype=torch.float64, device=dev)
+    o2 = torch.empty(4608, dtype=torch.float64, device=dev)
+    st = _lib.stream()
+    p = _lib.ptr
+    F = 2.0 * 64 * 64 * P          # flops of one 64x64 layer over all positions
+    kernels = {
+        "fwd2": (lambda: lib.facl_sa_fwd2(p(x), nunits, D, p(l1tab), p(W2), p(b2), p(dz2f), p(s64), p(ws), st), F),
+        "fwd3": (lambda: lib.facl_sa_fwd3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), st), 4 * F),
+        "bwd0": (lambda: lib.facl_sa_bwd0(p(coef), p(ymax), nunits, p(bnc3), p(coef), p(s256), p(ws), st), 0),
+        "bwd1": (lambda: lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg), p(dz2f), p(s64), p(ws), st), F),
+        "bwd_w3": (lambda: lib.facl_sa_bwd_w3(p(y2f), nunits, p(bnc2), p(coef), p(arg), p(o3), p(ws), st), 0.75 * F),
+        "bwd2": (lambda: lib.facl_sa_bwd2(p(dz2f), p(y2f), p(x), nunits, D, p(bw2), p(W2), p(l1tab), p(o2), p(ws), st), 2.5 * F),
+    }
+    for name, (fn, fl) in kernels.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        rc = fn()
+        assert rc == 0, (name, rc)
+        ms = timeit(fn)
+        print(f"{name:7s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TFLOP/s (MFMA work only)")
+
+
+if __name__ == "__main__":
+    main()

@@ -157,9 +157,11 @@ class PointNet_Plus(nn.Module):
             for i in (1, 4, 7):
                 self.net3DV_1[i].count_batch()
 
-        h = torch.cat((centers, pooled), 1)                                    # :219
-        for li in (0, 3):                                                      # net3DV_3 (:220)
-            h = _tail.linear_bn_relu(h, self.net3DV_3[li], self.net3DV_3[li + 1], training, self.bn_reduce_fn)
+        # net3DV_3 (:220).  torch.cat((yt, xt), 1) (:219) is never built: the first GEMM takes the centroid xyz as a
+        # rank-3 term in its epilogue
+        h = _tail.linear_bn_relu(pooled, self.net3DV_3[0], self.net3DV_3[1], training, self.bn_reduce_fn,
+                                 centers=centers)
+        h = _tail.linear_bn_relu(h, self.net3DV_3[3], self.net3DV_3[4], training, self.bn_reduce_fn)
         # last layer fused with my_max_pool (:222-223): xt_local (M,1024,S,1) is never materialised post-BN
         x_pre = _tail.linear_bn_relu_segmax(h, self.net3DV_3[6], self.net3DV_3[7], training, S, self.bn_reduce_fn)
         Bc = M // self.gost
@@ -175,7 +177,7 @@ class PointNet_Plus(nn.Module):
     def _fc(self, v, training):
         fc = self.netR_FC
         v = _tail.linear_bn_relu(v, fc[0], fc[1], training, self.bn_reduce_fn)
-        return torch.addmm(fc[3].bias, v, fc[3].weight.t())
+        return _tail.linear(v, fc[3])
 
 
 class PointNet_Plus_fine(PointNet_Plus):

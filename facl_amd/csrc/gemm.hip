@@ -1,0 +1,293 @@
+// fp32 MFMA GEMM for the dense 1x1 "point-MLP" channel contractions of the encoder tail
+// (net3DV_3 / netR_FC: cn3d_model_conbag.py:61-88), forward, dgrad and wgrad, with the BatchNorm plumbing
+// fused in:  * prologue  A' = relu(pscale[k]*A + pshift[k])  applied while the A tile is staged (forward),
+//            * epilogue  + bias[n], + rank-3 centre term (the xyz columns of torch.cat((yt, xt),1), :219),
+//                        per-column (sum, sumsq) partials for the train-mode BN that follows,
+//            * split-K partial tiles for the weight gradient (contraction over the 49,152 centroid rows).
+//
+//   C[i][j] = sum_k  opA(i,k) * opB(j,k)        i < MI, j < NJ, k < KK
+// Operand layouts (element (idx,k)):  KC ("k-contiguous")  ptr[idx*ld + k]   rows of activations / weights
+//                                     IC ("idx-contiguous") ptr[k*ld + idx]   the transposed views of dgrad/wgrad
+//   forward  y  = a W^T      : A = a  (KC), B = W (KC)
+//   dgrad    da = dy W       : A = dy (KC), B = W (IC)          (k = output channel)
+//   wgrad    dW = dy^T a     : A = dy (IC), B = a (IC)          (k = row, split over blockIdx.z)
+// Tile 128x128x32, 256 threads = 2x2 waves of 64x64 (2x2 v_mfma_f32_32x32x2_f32 tiles, 64 accumulators),
+// operands staged global -> registers -> LDS as [k][idx] (+4 pad) so that the MFMA fragments are
+// conflict-free ds_read_b32; register prefetch of the next k-tile overlaps the 64 MFMAs of the current one.
+// Roofline: MFMA fp32 (157.3 TFLOP/s); 2*MI*NJ*KK FLOP per call.
+#include "common.h"
+
+int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BM + 4;      // IC tiles: LDS image [k][idx], row = 132 floats (16-B aligned rows)
+constexpr int LDK = BK + 4;      // KC tiles: LDS image [idx][k], row = 36 floats: b128 writes AND b128 fragment reads
+                                 // are conflict-free (36*q mod 64 hits 16 distinct 4-dword slots for 16 lanes)
+constexpr int TILE_FLOATS = BM * LDK;        // 4608 >= BK*LDT = 4224
+enum { KC = 0, IC = 1 };
+
+struct GemmArgs {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int MI, NJ, KK;
+    const float* bias;                 // (NJ) or null
+    const float* pscale; const float* pshift;   // (KK) prologue on A, or null
+    const float* xa; const float* xb; int ldxb;  // rank-3 extra term: C += xa[i][0..2] . xb[j][0..2]  (or null)
+    double* part;                      // column statistics partials [(MI/64)][NJ][2], or null
+    int kchunk;                        // split-K: k range per blockIdx.z (wgrad); C then is [z][MI][NJ]
+};
+
+template <int LAY>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                          float4 (&r)[4], int tid) {
+    // 128 idx x 32 k = 1024 float4; thread t takes 4 of them
+    if (LAY == IC) {      // float4 along idx: (k = t/32 + 8*i, idx4 = t%32)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i, idx = idx0 + 4 * (tid & 31);
+            if (k < kend && idx + 3 < nidx) r[i] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + idx);
+            else {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (k < kend && idx + e < nidx) ? P[(size_t)k * ld + idx + e] : 0.f;
+                r[i] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    } else {              // float4 along k: 8 lanes cover one 128-B row segment (full cache lines per wave-instruction;
+                          // one-row-per-lane "fragment-shaped" loads touch 64 lines per instruction instead of 8)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = idx0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+            if (idx < nidx && k + 3 < kend) r[i] = *reinterpret_cast<const float4*>(P + (size_t)idx * ld + k);
+            else {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (idx < nidx && k + e < kend) ? P[(size_t)idx * ld + k + e] : 0.f;
+                r[i] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    }
+}
+
+template <int LAY, bool PRO>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[4], int tid, int k0,
+                                           const float* __restrict__ ps, const float* __restrict__ pt) {
+    if (LAY == IC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = (tid >> 5) + 8 * i;
+            *reinterpret_cast<float4*>(&T[k * LDT + 4 * (tid & 31)]) = r[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * (tid & 7), il = (tid >> 3) + 32 * i;
+            float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+            if (PRO) {
+                const float4 s = *reinterpret_cast<const float4*>(ps + k0 + k);
+                const float4 t = *reinterpret_cast<const float4*>(pt + k0 + k);
+                v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
+                v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
+            }
+            *reinterpret_cast<float4*>(&T[il * LDK + k]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int LA, int LB, bool PRO>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float sA[2][TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sB[2][TILE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    load_tile<LA>(g.A, g.lda, i0, g.MI, kbeg, kend, ra, tid);
+    load_tile<LB>(g.B, g.ldb, j0, g.NJ, kbeg, kend, rb, tid);
+    store_tile<LA, PRO>(sA[0], ra, tid, kbeg, g.pscale, g.pshift);
+    store_tile<LB, false>(sB[0], rb, tid, kbeg, nullptr, nullptr);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {
+            load_tile<LA>(g.A, g.lda, i0, g.MI, k0 + BK, kend, ra, tid);
+            load_tile<LB>(g.B, g.ldb, j0, g.NJ, k0 + BK, kend, rb, tid);
+        }
+        // MFMA k-slot of half h in step s is k = 16h + s for BOTH operands (any bijection works)
+        const float* pa = sA[cur];
+        const float* pb = sB[cur];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float a0[4], a1[4], b0[4], b1[4];
+            if (LA == KC) {
+                const float4 u = *reinterpret_cast<const float4*>(&pa[(64 * wr + q) * LDK + 16 * h + 4 * s4]);
+                const float4 v = *reinterpret_cast<const float4*>(&pa[(64 * wr + 32 + q) * LDK + 16 * h + 4 * s4]);
+                a0[0] = u.x; a0[1] = u.y; a0[2] = u.z; a0[3] = u.w; a1[0] = v.x; a1[1] = v.y; a1[2] = v.z; a1[3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = pa[(16 * h + 4 * s4 + e) * LDT + 64 * wr + q];
+                    a1[e] = pa[(16 * h + 4 * s4 + e) * LDT + 64 * wr + 32 + q];
+                }
+            }
+            if (LB == KC) {
+                const float4 u = *reinterpret_cast<const float4*>(&pb[(64 * wc + q) * LDK + 16 * h + 4 * s4]);
+                const float4 v = *reinterpret_cast<const float4*>(&pb[(64 * wc + 32 + q) * LDK + 16 * h + 4 * s4]);
+                b0[0] = u.x; b0[1] = u.y; b0[2] = u.z; b0[3] = u.w; b1[0] = v.x; b1[1] = v.y; b1[2] = v.z; b1[3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    b0[e] = pb[(16 * h + 4 * s4 + e) * LDT + 64 * wc + q];
+                    b1[e] = pb[(16 * h + 4 * s4 + e) * LDT + 64 * wc + 32 + q];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = MFMA32(a0[e], b0[e], acc[0][0]);
+                acc[0][1] = MFMA32(a0[e], b1[e], acc[0][1]);
+                acc[1][0] = MFMA32(a1[e], b0[e], acc[1][0]);
+                acc[1][1] = MFMA32(a1[e], b1[e], acc[1][1]);
+            }
+        }
+        if (more) {
+            store_tile<LA, PRO>(sA[cur ^ 1], ra, tid, k0 + BK, g.pscale, g.pshift);
+            store_tile<LB, false>(sB[cur ^ 1], rb, tid, k0 + BK, nullptr, nullptr);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  The accumulators hold (lane = column, register = row): column statistics are in-lane sums;
+    // the tile itself is transposed through LDS (the staging buffers are free now) so that it leaves as
+    // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound: 64 -> 16 store instructions per wave).
+    float* Cz = g.C + (size_t)blockIdx.z * g.MI * g.ldc;
+    float* stg = (wave < 2 ? sA[0] : sB[0]) + (wave & 1) * (64 * 68);     // 64 rows x 68 floats per wave (2 per array)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + 64 * wc + 32 * b + q;
+        const bool jin = j < g.NJ;
+        const float bias = (g.bias && jin) ? g.bias[j] : 0.f;
+        float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
+        if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
+        float s = 0.f, sq = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = 32 * a + rowmap(r, h);
+                const int i = i0 + 64 * wr + il;
+                float v = acc[a][b][r] + bias;
+                if (g.xa && i < g.MI)
+                    v = fmaf(g.xa[(size_t)i * 3], xb0, fmaf(g.xa[(size_t)i * 3 + 1], xb1, fmaf(g.xa[(size_t)i * 3 + 2], xb2, v)));
+                stg[il * 68 + 32 * b + q] = v;
+                if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
+            }
+        if (g.part) {
+            const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+            if (h == 0 && jin) {
+                double* pr = g.part + ((size_t)(blockIdx.y * 2 + wr) * g.NJ + j) * 2;
+                pr[0] = (double)st; pr[1] = (double)sqt;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // same-wave LDS hand-off (lanes swap roles)
+    const int jw = j0 + 64 * wc;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + 64 <= g.NJ);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int il = 4 * t + (lane >> 4), c4 = (lane & 15) * 4;
+        const int i = i0 + 64 * wr + il;
+        if (i >= g.MI) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&stg[il * 68 + c4]);
+        if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
+        else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
+        }
+    }
+}
+
+// sum over split-K slices: out[e] = sum_z part[z][e]
+__global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n4, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 s = reinterpret_cast<const float4*>(part)[i];
+        for (int z = 1; z < nz; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+template <int LA, int LB, bool PRO>
+int launch(const GemmArgs& g, int nz, hipStream_t st) {
+    dim3 grid((g.NJ + BN - 1) / BN, (g.MI + BM - 1) / BM, nz);
+    hipLaunchKernelGGL((k_gemm<LA, LB, PRO>), grid, dim3(256), 0, st, g);
+    return facl_launch_status();
+}
+
+}  // namespace
+
+// y (M,N) = opA(a) W^T + bias (+ centres term), optional BN+ReLU prologue on a, optional column statistics
+extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                             const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                             int ldwc, float* y, double* sums, void* ws, void* stream) {
+    if (!a || !W || !y || (sums && !ws)) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || K < 4 || (K & 3) || N < 1 || (ldw & 3)) return FACL_E_SHAPE;
+    if ((pscale == nullptr) != (pshift == nullptr) || (centers == nullptr) != (Wc == nullptr)) return FACL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, pscale, pshift, centers, Wc, ldwc,
+               sums ? (double*)ws : nullptr, K};
+    int rc = pscale ? launch<KC, KC, true>(g, 1, st) : launch<KC, KC, false>(g, 1, st);
+    if (rc || !sums) return rc;
+    const int prow = (int)((M + BM - 1) / BM) * 2;
+    if ((size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    // rows of the last (partial) tile that no wave wrote hold stale data only if M % 64 != 0 for the last
+    // wave-row; such partial rows contribute nothing because those waves stored s = sq = 0.
+    return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
+}
+
+// da (M,K) = dy (M,N) W (N,K)        (W row-major with leading dimension ldw; pass W + offset to skip columns)
+extern "C" int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
+                               void* stream) {
+    if (!dy || !W || !da) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 1) return FACL_E_SHAPE;
+    GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N};
+    return launch<KC, IC, false>(g, 1, (hipStream_t)stream);
+}
+
+// dW (N,K) = dy^T (N,M) a (M,K), split over nz row chunks; `slices` is scratch for nz*N*K floats
+extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                               float* slices, int nz, void* stream) {
+    if (!dy || !a || !dW || !slices) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk = (int)((M + nz - 1) / nz);
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    nz = (int)((M + kchunk - 1) / kchunk);
+    GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk};
+    int rc = launch<IC, IC, false>(g, nz, st);
+    if (rc) return rc;
+    const long long n4 = (long long)N * K / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid), dim3(256), 0, st, slices, nz, n4, dW);
+    return facl_launch_status();
+}

@@ -1,14 +1,54 @@
 """Encoder tail (net3DV_3, my_max_pool, netR_FC: cn3d_model_conbag.py:61-88, :199-207).
 
-Per layer: one plain library GEMM (rocBLAS via torch.mm -- the 1x1 conv over (M*S) centroid rows IS a
-dense GEMM) + hand-written HIP kernels for everything around it: train-mode BN statistics (fp64 sums,
-SyncBN hook), BN+ReLU apply, BN+ReLU+max over the S centroids without materialising the activation,
-and the matching backward passes (csrc/rows.hip).
+Per layer: the dense 1x1 channel contraction runs on the hand-written fp32 MFMA GEMM (csrc/gemm.hip: forward with
+fused bias / centre term / BN column statistics, dgrad, split-K wgrad); train-mode BN finalisation (fp64 sums,
+SyncBN hook), BN+ReLU apply, BN+ReLU+max over the S centroids without materialising the activation, and the
+matching backward passes are the row kernels of csrc/rows.hip.
 """
 import torch
 
 from . import _lib
 from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
+
+
+def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
+    """y = a W^T + bias [+ centers Wc^T] on the hand-written fp32 MFMA GEMM (csrc/gemm.hip); optional fused
+    column (sum, sumsq) for the BatchNorm that follows."""
+    lib = _lib.load_library()
+    M, K = a.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    sums = torch.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
+    ws = _Workspace.get(a.device)
+    _lib.check(lib.facl_gemm_fwd(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
+                                 _lib.ptr(centers), _lib.ptr(Wc), 3 if Wc is not None else 0, _lib.ptr(y),
+                                 _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_gemm_fwd")
+    return y, sums
+
+
+def gemm_dgrad(dy, W):
+    """da = dy W   (W (N,K) row-major, possibly a column slice of a wider matrix)."""
+    lib = _lib.load_library()
+    M, N = dy.shape
+    K = W.shape[1]
+    da = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
+               "facl_gemm_dgrad")
+    return da
+
+
+def gemm_wgrad(dy, a):
+    """dW = dy^T a, contraction over the rows split into slices (deterministic slice-order sum)."""
+    lib = _lib.load_library()
+    M, N = dy.shape
+    K = a.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    nz = max(1, min((M + 255) // 256, 768 // tiles))
+    dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    slices = torch.empty(nz * N * K, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
+                                   _lib.stream()), "facl_gemm_wgrad")
+    return dW
 
 
 def _stats(y, ws):
@@ -19,12 +59,13 @@ def _stats(y, ws):
     return sums
 
 
-def _forward_bn_consts(y, bn, training, reduce_fn, ws):
+def _forward_bn_consts(y, bn, training, reduce_fn, ws, sums=None):
     """Statistics -> (5,C) constants; updates running stats / num_batches_tracked in training mode."""
     R, C = y.shape
     if not training:
         return _bn_eval(C, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var), float(R)
-    sums = _stats(y, ws)
+    if sums is None:
+        sums = _stats(y, ws)
     count = float(R)
     if reduce_fn is not None:
         reduce_fn(sums)
@@ -35,14 +76,24 @@ def _forward_bn_consts(y, bn, training, reduce_fn, ws):
 
 
 class _LinearBNReLU(torch.autograd.Function):
+    """relu(bn(h W^T + b)); with ``centers`` the input is the (never materialised) torch.cat((yt, xt), 1) of
+    cn3d_model_conbag.py:219: W's first 3 columns act on the centroid xyz, the rest on ``h``."""
+
     @staticmethod
-    def forward(ctx, h, W, b, gamma, beta, bn, training, reduce_fn):
+    def forward(ctx, h, W, b, gamma, beta, bn, training, reduce_fn, centers=None):
         lib = _lib.load_library()
         _lib.require_cuda(h)
         ws = _Workspace.get(h.device)
         h = h.contiguous()
-        y = torch.addmm(b, h, W.t())                                   # library GEMM
-        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws)
+        if centers is not None:
+            Wc, Wh = W[:, :3].contiguous(), W[:, 3:].contiguous()
+            centers = centers.contiguous()
+        else:
+            Wc, Wh = None, W.contiguous()
+        y, sums = gemm_fwd(h, Wh, b, want_stats=training, centers=centers, Wc=Wc)
+        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
+        ctx.centers = centers
+        ctx.Wh = Wh
         R, C = y.shape
         a = torch.empty_like(y)
         _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y), R, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a),
@@ -72,10 +123,12 @@ class _LinearBNReLU(torch.autograd.Function):
         dy = torch.empty_like(y)
         _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                            _lib.stream()), "facl_rows_bwd_apply")
-        dW = dy.t() @ h                                                 # library GEMMs
-        dh = dy @ W if ctx.needs_input_grad[0] else None
+        dW = gemm_wgrad(dy, h)
+        if ctx.centers is not None:                                     # xyz columns: (C,3), negligible
+            dW = torch.cat((dy.t() @ ctx.centers, dW), dim=1)
+        dh = gemm_dgrad(dy, ctx.Wh) if ctx.needs_input_grad[0] else None
         # d(bias) is identically zero in front of a train-mode BN: None leaves the parameter untouched
-        return dh, dW, None, dgamma, dbeta, None, None, None
+        return dh, dW, None, dgamma, dbeta, None, None, None, None
 
 
 class _LinearBNSegmax(torch.autograd.Function):
@@ -87,8 +140,9 @@ class _LinearBNSegmax(torch.autograd.Function):
         _lib.require_cuda(h)
         ws = _Workspace.get(h.device)
         h = h.contiguous()
-        y = torch.addmm(b, h, W.t())
-        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws)
+        W = W.contiguous()
+        y, sums = gemm_fwd(h, W, b, want_stats=training)
+        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
         R, C = y.shape
         M = R // S
         xpre = torch.empty((M, C), dtype=torch.float32, device=y.device)
@@ -125,15 +179,36 @@ class _LinearBNSegmax(torch.autograd.Function):
         _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), _lib.stream()),
                    "facl_segmax_bwd_apply")
-        dW = dy.t() @ h
-        dh = dy @ W
+        dW = gemm_wgrad(dy, h)
+        dh = gemm_dgrad(dy, W)
         return dh, dW, None, dgamma, dbeta, None, None, None, None
 
 
-def linear_bn_relu(h, affine, bn, training, reduce_fn=None):
-    """relu(bn(h W^T + b)) over rows; W is (Cout,Cin[,1,1])."""
+def linear_bn_relu(h, affine, bn, training, reduce_fn=None, centers=None):
+    """relu(bn([centers | h] W^T + b)) over rows; W is (Cout,Cin[,1,1])."""
     W = affine.weight.view(affine.weight.shape[0], -1)
-    return _LinearBNReLU.apply(h, W, affine.bias, bn.weight, bn.bias, bn, training, reduce_fn)
+    return _LinearBNReLU.apply(h, W, affine.bias, bn.weight, bn.bias, bn, training, reduce_fn, centers)
+
+
+class _Linear(torch.autograd.Function):
+    """Plain h W^T + b on the MFMA GEMMs (netR_FC.3, cn3d_model_conbag.py:206)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        h, W = h.contiguous(), W.contiguous()
+        y, _ = gemm_fwd(h, W, b)
+        ctx.save_for_backward(h, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        return gemm_dgrad(dy, W), gemm_wgrad(dy, h), dy.sum(0)
+
+
+def linear(h, affine):
+    return _Linear.apply(h, affine.weight, affine.bias)
 
 
 def linear_bn_relu_segmax(h, affine, bn, training, S, reduce_fn=None):

@@ -168,6 +168,21 @@ int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y,
 int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                           int64_t M, int S, int C, const float* bnc, const float* kk, float* dy, void* stream);
 
+/* ---- fp32 MFMA GEMMs of the tail's dense 1x1 channel contractions (csrc/gemm.hip) ------------------
+ * Weights are the checkpoint tensors, row-major (Cout,Cin) with leading dimension ldw (multiple of 4).
+ *   facl_gemm_fwd    y (M,N) = a' W^T + bias [+ centers (M,3) Wc (N,ldwc)^T], a' = a or relu(pscale*a+pshift);
+ *                    sums (N,2) = column (sum, sumsq) of y for the BN that follows (or NULL)
+ *   facl_gemm_dgrad  da (M,K) = dy (M,N) W (N,K)
+ *   facl_gemm_wgrad  dW (N,K) = dy^T a, contraction over the M rows split into nz slices
+ *                    (`slices` = scratch of nz*N*K floats), summed in slice order (deterministic) */
+int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                  const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                  int ldwc, float* y, double* sums, void* ws, void* stream);
+int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
+                    void* stream);
+int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                    float* slices, int nz, void* stream);
+
 /* ---- contrastive losses on a similarity matrix (utils_my.py:53-116) ----------------------------
  * sim (R,J) = anchors @ keys^T, R = nA*B rows (row i*B+n: clip n), J = G*Bk columns (column j belongs to
  * clip j % Bk).  Same-clip columns count as exp(0) (the reference multiplies them by 0); the nA rows of a

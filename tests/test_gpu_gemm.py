@@ -1,0 +1,75 @@
+"""GPU parity of the fp32 MFMA GEMMs (forward with fused prologue/epilogue, dgrad, split-K wgrad) vs fp64."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ws():
+    from facl_amd.sa_mlp import _Workspace
+    return _Workspace.get(torch.device(DEV))
+
+
+@pytest.mark.parametrize("M,K,N,pro,ctr", [(256, 64, 128, False, False), (4096, 256, 256, True, True),
+                                           (1000, 512, 384, True, False), (32, 1024, 1024, False, False),
+                                           (768, 1024, 512, False, False), (130, 36, 200, True, True)])
+def test_gemm_fwd(M, K, N, pro, ctr):
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    ps = torch.rand(K, device=DEV, generator=g) + 0.5 if pro else None
+    pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
+    cen = torch.randn(M, 3, device=DEV, generator=g) if ctr else None
+    Wc = torch.randn(N, 3, device=DEV, generator=g) if ctr else None
+    y = torch.empty(M, N, device=DEV)
+    sums = torch.empty(N, 2, dtype=torch.float64, device=DEV)
+    p = _lib.ptr
+    _lib.check(lib.facl_gemm_fwd(p(a), M, K, p(W), K, N, p(b), p(ps), p(pt), p(cen), p(Wc), 3, p(y), p(sums), p(_ws()),
+                                 _lib.stream()), "gemm_fwd")
+    a64 = a.double()
+    if pro:
+        a64 = torch.relu(a64 * ps.double() + pt.double())
+    ref = a64 @ W.double().t() + b.double()
+    if ctr:
+        ref = ref + cen.double() @ Wc.double().t()
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert rel_err(sums[:, 0].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-5 * max(1.0, float(ref.abs().sum(0).max() / ref.sum(0).abs().max()))
+    assert rel_err(sums[:, 1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,ldw,off", [(4096, 256, 256, 256, 0), (1000, 384, 520, 523 + 1, 4), (32, 512, 1024, 1024, 0),
+                                           (49152 // 8, 1024, 512, 512, 0)])
+def test_gemm_dgrad(M, N, K, ldw, off):
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    Wfull = torch.randn(N, ldw, device=DEV, generator=g) / N ** 0.5
+    W = Wfull[:, off:off + K]
+    da = torch.empty(M, K, device=DEV)
+    _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, W.data_ptr(), ldw, K, _lib.ptr(da), _lib.stream()), "dgrad")
+    ref = dy.double() @ W.double()
+    assert rel_err(da.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,nz", [(4096, 256, 256, 4), (49152 // 4, 512, 256, 12), (1000, 128, 384, 3), (32, 1024, 1024, 1),
+                                      (768, 512, 1024, 2)])
+def test_gemm_wgrad(M, N, K, nz):
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    dW = torch.empty(N, K, device=DEV)
+    slices = torch.empty(nz * N * K, device=DEV)
+    _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, K, _lib.ptr(dW), _lib.ptr(slices), nz,
+                                   _lib.stream()), "wgrad")
+    ref = dy.double().t() @ a.double()
+    assert rel_err(dW.cpu().numpy(), ref.cpu().numpy()) < 3e-6

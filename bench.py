@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--N", type=int, default=2048)
     ap.add_argument("--D", type=int, default=3, help="input channels (north_star: 3-ch; checkpoints: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (single GPU only)")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -131,18 +132,27 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from facl_amd.cn3d_model_conbag import PointNet_Plus
-    from facl_amd.train_common import ContrastiveStep, synthetic_batch
+    from facl_amd.train_common import ContrastiveStep, GraphedStep, synthetic_batch
 
     torch.manual_seed(1)                       # opt.manualSeed = 1 (cn3d_train_motion_GL.py:142-144)
     np.random.seed(1)
     opt = make_opt(a)
     net = PointNet_Plus(opt, gost=a.T).to(dev).train()
     net.bn_reduce_fn = fdist.make_bn_reduce_fn()
-    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
+    use_graph = bool(a.graph) and world == 1
+    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, capturable=use_graph)
     step = ContrastiveStep(net, optim, opt, a.T)
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]   # resident in HBM
+    mode = "eager"
+    if use_graph:
+        try:
+            step = GraphedStep(step, batches[0], a.T)
+            mode = "hipgraph"
+        except Exception as e:                          # never lose the measurement to a capture problem
+            print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+            net.zero_grad(set_to_none=True)
 
     def barrier():
         if world > 1:
@@ -171,7 +181,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"motion stream, B={a.B}/GPU T={a.T} N={a.N} D={a.D}, S=64 K=64, full "
                                       f"cn3d_model_conbag encoder, global+circle loss, backward, Adam",
-                          "global_batch": a.B * world, "parallelism": f"dp{world}"},
+                          "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode},
                "final_loss": final_loss}
         out["roofline"] = dominant_kernel_roofline(a, dev)
         if world == 1 and not a.no_cpu_baseline:

@@ -141,6 +141,9 @@ class PointNet_Plus(nn.Module):
             raise RuntimeError("input has %d channels, model was built for %d" % (D, self.INPUT_FEATURE_NUM))
         if K != self._pool_K:
             raise RuntimeError("pooling window is %d neighbours, got K=%d" % (self._pool_K, K))
+        if K != sa_mlp.UNIT:
+            raise NotImplementedError("the HIP set-abstraction kernels are built for knn_K = 64 (one 64-position unit per "
+                                      "group); K=%d is not implemented yet" % K)
         if S != self._pool_S:
             raise RuntimeError("model pools over %d centroids, got S=%d" % (self._pool_S, S))
         if M % self.gost:

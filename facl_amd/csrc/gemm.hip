@@ -21,11 +21,10 @@ int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDT = BM + 4;      // IC tiles: LDS image [k][idx], row = 132 floats (16-B aligned rows)
+constexpr int BK = 32;
 constexpr int LDK = BK + 4;      // KC tiles: LDS image [idx][k], row = 36 floats: b128 writes AND b128 fragment reads
                                  // are conflict-free (36*q mod 64 hits 16 distinct 4-dword slots for 16 lanes)
-constexpr int TILE_FLOATS = BM * LDK;        // 4608 >= BK*LDT = 4224
+// IC tiles: LDS image [k][idx], row = NIDX+4 floats (16-B aligned rows).  NIDX = 64*T (T = 32x32 tiles per wave side)
 enum { KC = 0, IC = 1 };
 
 struct GemmArgs {
@@ -40,14 +39,14 @@ struct GemmArgs {
     int kchunk;                        // split-K: k range per blockIdx.z (wgrad); C then is [z][MI][NJ]
 };
 
-template <int LAY>
+template <int LAY, int T>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
-                                          float4 (&r)[4], int tid) {
-    // 128 idx x 32 k = 1024 float4; thread t takes 4 of them
-    if (LAY == IC) {      // float4 along idx: (k = t/32 + 8*i, idx4 = t%32)
+                                          float4 (&r)[2 * T], int tid) {
+    // (64T) idx x 32 k = 512T float4; thread t takes 2T of them
+    if (LAY == IC) {      // float4 along idx: 16T float4 per k-row
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (tid >> 5) + 8 * i, idx = idx0 + 4 * (tid & 31);
+        for (int i = 0; i < 2 * T; ++i) {
+            const int k = k0 + tid / (16 * T) + (16 / T) * i, idx = idx0 + 4 * (tid % (16 * T));
             if (k < kend && idx + 3 < nidx) r[i] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + idx);
             else {
                 float t[4];
@@ -59,7 +58,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     } else {              // float4 along k: 8 lanes cover one 128-B row segment (full cache lines per wave-instruction;
                           // one-row-per-lane "fragment-shaped" loads touch 64 lines per instruction instead of 8)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * T; ++i) {
             const int idx = idx0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
             if (idx < nidx && k + 3 < kend) r[i] = *reinterpret_cast<const float4*>(P + (size_t)idx * ld + k);
             else {
@@ -72,18 +71,19 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
-template <int LAY, bool PRO>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[4], int tid, int k0,
+template <int LAY, bool PRO, int TT>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[2 * TT], int tid, int k0,
                                            const float* __restrict__ ps, const float* __restrict__ pt) {
+    constexpr int LDT = 64 * TT + 4;
     if (LAY == IC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = (tid >> 5) + 8 * i;
-            *reinterpret_cast<float4*>(&T[k * LDT + 4 * (tid & 31)]) = r[i];
+        for (int i = 0; i < 2 * TT; ++i) {
+            const int k = tid / (16 * TT) + (16 / TT) * i;
+            *reinterpret_cast<float4*>(&T[k * LDT + 4 * (tid % (16 * TT))]) = r[i];
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * TT; ++i) {
             const int k = 4 * (tid & 7), il = (tid >> 3) + 32 * i;
             float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
             if (PRO) {
@@ -97,76 +97,83 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
     }
 }
 
-template <int LA, int LB, bool PRO>
+template <int LA, int LB, bool PRO, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float sA[2][TILE_FLOATS];
-    __shared__ __attribute__((aligned(16))) float sB[2][TILE_FLOATS];
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;
+    constexpr int AF = (LA == KC) ? BM * LDK : BK * LDA, BF = (LB == KC) ? BN * LDK : BK * LDB;
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);                 // epilogue staging: 4 waves x rows x padded cols
+    constexpr int SMEM = (2 * (AF + BF) > STG) ? 2 * (AF + BF) : STG;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const sA0 = smem;                     // stage s of A at sA0 + s*AF, of B at sB0 + s*BF
+    float* const sB0 = smem + 2 * AF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra[4], rb[4];
-    load_tile<LA>(g.A, g.lda, i0, g.MI, kbeg, kend, ra, tid);
-    load_tile<LB>(g.B, g.ldb, j0, g.NJ, kbeg, kend, rb, tid);
-    store_tile<LA, PRO>(sA[0], ra, tid, kbeg, g.pscale, g.pshift);
-    store_tile<LB, false>(sB[0], rb, tid, kbeg, nullptr, nullptr);
+    float4 ra[2 * TM], rb[2 * TN];
+    load_tile<LA, TM>(g.A, g.lda, i0, g.MI, kbeg, kend, ra, tid);
+    load_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, kbeg, kend, rb, tid);
+    store_tile<LA, PRO, TM>(sA0, ra, tid, kbeg, g.pscale, g.pshift);
+    store_tile<LB, false, TN>(sB0, rb, tid, kbeg, nullptr, nullptr);
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            load_tile<LA>(g.A, g.lda, i0, g.MI, k0 + BK, kend, ra, tid);
-            load_tile<LB>(g.B, g.ldb, j0, g.NJ, k0 + BK, kend, rb, tid);
+            load_tile<LA, TM>(g.A, g.lda, i0, g.MI, k0 + BK, kend, ra, tid);
+            load_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, k0 + BK, kend, rb, tid);
         }
         // MFMA k-slot of half h in step s is k = 16h + s for BOTH operands (any bijection works)
-        const float* pa = sA[cur];
-        const float* pb = sB[cur];
+        const float* pa = sA0 + cur * AF;
+        const float* pb = sB0 + cur * BF;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            float a0[4], a1[4], b0[4], b1[4];
+            float av[TM][4], bv[TN][4];
+            // KC operands: one b128 read fetches this lane's 4 consecutive k of the step group;
+            // IC operands are read one k at a time right before their MFMAs (finer LDS / MFMA interleave)
             if (LA == KC) {
-                const float4 u = *reinterpret_cast<const float4*>(&pa[(64 * wr + q) * LDK + 16 * h + 4 * s4]);
-                const float4 v = *reinterpret_cast<const float4*>(&pa[(64 * wr + 32 + q) * LDK + 16 * h + 4 * s4]);
-                a0[0] = u.x; a0[1] = u.y; a0[2] = u.z; a0[3] = u.w; a1[0] = v.x; a1[1] = v.y; a1[2] = v.z; a1[3] = v.w;
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0[e] = pa[(16 * h + 4 * s4 + e) * LDT + 64 * wr + q];
-                    a1[e] = pa[(16 * h + 4 * s4 + e) * LDT + 64 * wr + 32 + q];
+                for (int a = 0; a < TM; ++a) {
+                    const float4 u = *reinterpret_cast<const float4*>(&pa[(32 * TM * wr + 32 * a + q) * LDK + 16 * h + 4 * s4]);
+                    av[a][0] = u.x; av[a][1] = u.y; av[a][2] = u.z; av[a][3] = u.w;
                 }
             }
             if (LB == KC) {
-                const float4 u = *reinterpret_cast<const float4*>(&pb[(64 * wc + q) * LDK + 16 * h + 4 * s4]);
-                const float4 v = *reinterpret_cast<const float4*>(&pb[(64 * wc + 32 + q) * LDK + 16 * h + 4 * s4]);
-                b0[0] = u.x; b0[1] = u.y; b0[2] = u.z; b0[3] = u.w; b1[0] = v.x; b1[1] = v.y; b1[2] = v.z; b1[3] = v.w;
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    b0[e] = pb[(16 * h + 4 * s4 + e) * LDT + 64 * wc + q];
-                    b1[e] = pb[(16 * h + 4 * s4 + e) * LDT + 64 * wc + 32 + q];
+                for (int b = 0; b < TN; ++b) {
+                    const float4 u = *reinterpret_cast<const float4*>(&pb[(32 * TN * wc + 32 * b + q) * LDK + 16 * h + 4 * s4]);
+                    bv[b][0] = u.x; bv[b][1] = u.y; bv[b][2] = u.z; bv[b][3] = u.w;
                 }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = MFMA32(a0[e], b0[e], acc[0][0]);
-                acc[0][1] = MFMA32(a0[e], b1[e], acc[0][1]);
-                acc[1][0] = MFMA32(a1[e], b0[e], acc[1][0]);
-                acc[1][1] = MFMA32(a1[e], b1[e], acc[1][1]);
+                if (LA == IC) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) av[a][e] = pa[(16 * h + 4 * s4 + e) * LDA + 32 * TM * wr + 32 * a + q];
+                }
+                if (LB == IC) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bv[b][e] = pb[(16 * h + 4 * s4 + e) * LDB + 32 * TN * wc + 32 * b + q];
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(av[a][e], bv[b][e], acc[a][b]);
             }
         }
         if (more) {
-            store_tile<LA, PRO>(sA[cur ^ 1], ra, tid, k0 + BK, g.pscale, g.pshift);
-            store_tile<LB, false>(sB[cur ^ 1], rb, tid, k0 + BK, nullptr, nullptr);
+            store_tile<LA, PRO, TM>(sA0 + (cur ^ 1) * AF, ra, tid, k0 + BK, g.pscale, g.pshift);
+            store_tile<LB, false, TN>(sB0 + (cur ^ 1) * BF, rb, tid, k0 + BK, nullptr, nullptr);
         }
         __syncthreads();
         cur ^= 1;
@@ -174,27 +181,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 
     // ---- epilogue.  The accumulators hold (lane = column, register = row): column statistics are in-lane sums;
     // the tile itself is transposed through LDS (the staging buffers are free now) so that it leaves as
-    // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound: 64 -> 16 store instructions per wave).
+    // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound).
+    constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
     float* Cz = g.C + (size_t)blockIdx.z * g.MI * g.ldc;
-    float* stg = (wave < 2 ? sA[0] : sB[0]) + (wave & 1) * (64 * 68);     // 64 rows x 68 floats per wave (2 per array)
+    float* stg = smem + wave * (WR * SP);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int j = j0 + 64 * wc + 32 * b + q;
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + WC * wc + 32 * b + q;
         const bool jin = j < g.NJ;
         const float bias = (g.bias && jin) ? g.bias[j] : 0.f;
         float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
         if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
         float s = 0.f, sq = 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int il = 32 * a + rowmap(r, h);
-                const int i = i0 + 64 * wr + il;
+                const int i = i0 + WR * wr + il;
                 float v = acc[a][b][r] + bias;
                 if (g.xa && i < g.MI)
                     v = fmaf(g.xa[(size_t)i * 3], xb0, fmaf(g.xa[(size_t)i * 3 + 1], xb1, fmaf(g.xa[(size_t)i * 3 + 2], xb2, v)));
-                stg[il * 68 + 32 * b + q] = v;
+                stg[il * SP + 32 * b + q] = v;
                 if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
             }
         if (g.part) {
@@ -206,14 +214,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // same-wave LDS hand-off (lanes swap roles)
-    const int jw = j0 + 64 * wc;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + 64 <= g.NJ);
+    const int jw = j0 + WC * wc;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + WC <= g.NJ);
+    constexpr int LPR = WC / 4;                                            // lanes per row (float4 each)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int il = 4 * t + (lane >> 4), c4 = (lane & 15) * 4;
-        const int i = i0 + 64 * wr + il;
+    for (int t = 0; t < WR * LPR / 64; ++t) {
+        const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
+        const int i = i0 + WR * wr + il;
         if (i >= g.MI) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&stg[il * 68 + c4]);
+        const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
         if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
         else {
             const float e[4] = {v.x, v.y, v.z, v.w};
@@ -237,10 +246,20 @@ __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n
     }
 }
 
+// tile choice: 128x128 blocks when they already fill the chip, else 64x64 blocks (4x the workgroups) -- the FC head
+// (M = 768 or 32 rows) would otherwise run on 48 or 8 of the 256 CUs
 template <int LA, int LB, bool PRO>
-int launch(const GemmArgs& g, int nz, hipStream_t st) {
-    dim3 grid((g.NJ + BN - 1) / BN, (g.MI + BM - 1) / BM, nz);
-    hipLaunchKernelGGL((k_gemm<LA, LB, PRO>), grid, dim3(256), 0, st, g);
+int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
+    const long long big = (long long)((g.NJ + 127) / 128) * ((g.MI + 127) / 128) * nz;
+    if (big >= 256) {
+        dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+        hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
+        if (rows_per_part) *rows_per_part = 64;
+    } else {
+        dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+        hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
+        if (rows_per_part) *rows_per_part = 32;
+    }
     return facl_launch_status();
 }
 
@@ -256,9 +275,10 @@ extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, i
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, pscale, pshift, centers, Wc, ldwc,
                sums ? (double*)ws : nullptr, K};
-    int rc = pscale ? launch<KC, KC, true>(g, 1, st) : launch<KC, KC, false>(g, 1, st);
+    int rpp = 64;
+    int rc = pscale ? launch<KC, KC, true>(g, 1, st, &rpp) : launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
-    const int prow = (int)((M + BM - 1) / BM) * 2;
+    const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
     if ((size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     // rows of the last (partial) tile that no wave wrote hold stale data only if M % 64 != 0 for the last
     // wave-row; such partial rows contribute nothing because those waves stored s = sq = 0.
@@ -271,7 +291,7 @@ extern "C" int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W
     if (!dy || !W || !da) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 1) return FACL_E_SHAPE;
     GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N};
-    return launch<KC, IC, false>(g, 1, (hipStream_t)stream);
+    return launch<KC, IC, false>(g, 1, (hipStream_t)stream, nullptr);
 }
 
 // dW (N,K) = dy^T (N,M) a (M,K), split over nz row chunks; `slices` is scratch for nz*N*K floats
@@ -284,7 +304,7 @@ extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N
     kchunk = (kchunk + BK - 1) / BK * BK;
     nz = (int)((M + kchunk - 1) / kchunk);
     GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk};
-    int rc = launch<IC, IC, false>(g, nz, st);
+    int rc = launch<IC, IC, false>(g, nz, st, nullptr);
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);

@@ -55,6 +55,8 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
     P, D = x_rows.shape
     if P % UNIT:
         raise ValueError("P must be a multiple of 64 (knn_K = 64)")
+    if D not in (3, 4):
+        raise NotImplementedError("INPUT_FEATURE_NUM must be 3 or 4 (got %d)" % D)
     nunits = P // UNIT
     dev = x_rows.device
     st = _lib.stream()

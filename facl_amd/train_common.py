@@ -86,14 +86,22 @@ class ContrastiveStep:
     def __call__(self, out_points, epoch=0, order=None):
         netR, G = self.netR, self.G
         B, G_, N, D = out_points.shape
+        if order is None:
+            order = np.arange(0, G, 1)
+            np.random.shuffle(order)                                               # :297-298
+        if not torch.is_tensor(order):
+            order = torch.as_tensor(np.asarray(order), dtype=torch.long).to(out_points.device)
+        return self.run(out_points, order)
+
+    def run(self, out_points, order):
+        """Device-only body (no host round trips): this is what GraphedStep captures into a HIP graph."""
+        netR, G = self.netR, self.G
+        B, G_, N, D = out_points.shape
         data1 = out_points.permute(1, 0, 2, 3).reshape(-1, N, D).float()          # :226-228 (view-major rows)
         xt, yt = self.group(data1)
         x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
         x_keys = fdist.all_gather_view_major(x, G)
         off = self.rank * B
-        if order is None:
-            order = np.arange(0, G, 1)
-            np.random.shuffle(order)                                               # :297-298
         # global (:265-287) + circle (:290-316) losses: similarity GEMMs + one HIP kernel each (csrc/loss.hip)
         loss_c, loss_circle = contrastive_losses(G, x_global, x, order, x_keys=x_keys, clip_offset=off)
         loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0)
@@ -102,6 +110,43 @@ class ContrastiveStep:
         fdist.allreduce_gradients(netR.parameters())
         self.optimizer.step()
         return loss, loss_c, loss_circle
+
+
+class GraphedStep:
+    """The whole training iteration (grouping -> forward -> losses -> backward -> Adam) captured once into a HIP
+    graph and replayed: ~250 kernel launches per step collapse into one graph launch, so the step is no longer bound
+    by host launch latency.  Single-GPU only (collectives stay eager); needs Adam(capturable=True)."""
+
+    def __init__(self, step, example_points, G):
+        self.step, self.G = step, G
+        dev = example_points.device
+        self.points = example_points.clone()
+        self.order = torch.arange(G, dtype=torch.long, device=dev)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                       # warm-up on a side stream (allocator + lazy inits)
+            for _ in range(3):
+                step.run(self.points, self.order)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step.run(self.points, self.order)
+
+    def _bn_modules(self):
+        return [m for m in self.step.netR.modules() if hasattr(m, "count_batch")]
+
+    def __call__(self, out_points, epoch=0, order=None):
+        if order is None:
+            order = np.arange(0, self.G, 1)
+            np.random.shuffle(order)
+        self.points.copy_(out_points, non_blocking=True)
+        self.order.copy_(torch.as_tensor(np.asarray(order), dtype=torch.long), non_blocking=True)
+        self.graph.replay()
+        for m in self._bn_modules():                     # host-side num_batches_tracked (netR_FC.1 counts twice)
+            m.count_batch()
+        self.step.netR.netR_FC[1].count_batch()
+        return self.out
 
 
 def lr_for_epoch(base_lr, epoch, step_size=4, gamma=0.7):

@@ -178,7 +178,8 @@ class _ContrastiveLosses(torch.autograd.Function):
 def contrastive_losses(num_crop, x_global, x, order, x_keys=None, clip_offset=0):
     """(loss_c, loss_circle) = (global_contrast(...), circle_contrast(...)) through the HIP loss kernel."""
     keys = x if x_keys is None else x_keys
-    order = torch.as_tensor(order, device=x.device, dtype=torch.long)
+    if not (torch.is_tensor(order) and order.device == x.device and order.dtype == torch.long):
+        order = torch.as_tensor(order, device=x.device, dtype=torch.long)
     if keys is x:
         keys = x.view_as(x)            # distinct autograd input so that d_keys and d_x accumulate separately
     return _ContrastiveLosses.apply(x_global, x, keys, order, num_crop, clip_offset)

@@ -1,0 +1,86 @@
+"""End-to-end entries on the GPU: training entry -> checkpoint -> extraction entry, the HIP-graph
+replay of the step, and checkpoint compatibility with the reference's key names."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_train_entry_checkpoint_then_extract(tmp_path):
+    from facl_amd import cn3d_train_motion_GL as train, extract_motion_feature as ext
+    from oracle.weights import state_dict_shapes
+    ck = str(tmp_path / "ck")
+    net = train.main(["--batchSize", "4", "--nepoch", "1", "--steps_per_epoch", "2", "--num_crop", "4", "--SAMPLE_NUM", "512",
+                      "--save_root_dir", ck, "--INPUT_FEATURE_NUM", "4"])
+    path = os.path.join(ck, "corr_GL_0.pth")                           # reference checkpoint name (:341)
+    assert os.path.exists(path)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == [k for k, _ in state_dict_shapes(4)]     # the reference's 52 keys, in order
+    assert int(sd["net3DV_1.1.num_batches_tracked"]) == 2 and int(sd["netR_FC.1.num_batches_tracked"]) == 4
+    feats = ext.main(["--checkpoint", path, "--batchSize", "3", "--num_crop", "4", "--SAMPLE_NUM", "512",
+                      "--INPUT_FEATURE_NUM", "4", "--num_batches", "2", "--save_path", str(tmp_path / "f")])
+    assert feats.shape == (6, 5 * 512) and np.isfinite(feats).all()
+    one = np.load(str(tmp_path / "f" / "synthetic_0000_000.npy"))
+    assert one.shape == (5 * 512,) and one.dtype == np.float32
+
+    # the extraction forward equals the oracle's eval-mode forward on the same checkpoint
+    from facl_amd.extract_common import extract_batch, save_single_feature
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from oracle import encoder as E, grouping as OG
+    opt = SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                          sample_num_level2=64, INPUT_FEATURE_NUM=4, Num_Class=512, batchSize=3, pooling="concatenation",
+                          SAMPLE_NUM=512)
+    m = PointNet_Plus(opt, gost=4)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    torch.manual_seed(0)
+    clip = torch.rand(3, 4, 512, 4) - 0.5
+    with torch.no_grad():
+        f = extract_batch(m, clip.to(DEV), opt).cpu().numpy()
+    pts = clip.permute(1, 0, 2, 3).reshape(-1, 512, 4).numpy()
+    _, xt, yt = OG.group_points(pts, 64, 64, 0.06)
+    sdo = {k: v.double() if v.is_floating_point() else v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        x, _, _, xg = E.encoder_forward(sdo, torch.from_numpy(xt).permute(0, 3, 1, 2).double(),
+                                        torch.from_numpy(yt).view(12, 1, 64, 3).transpose(1, 3).double(), 4, training=False)
+    ref = save_single_feature(torch.cat((x, xg), 0).numpy(), str(tmp_path), ["a", "b", "c"], num_crop=5)
+    err = np.linalg.norm(f - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 1e-4, err
+
+
+def test_graph_replay_equals_eager():
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.train_common import ContrastiveStep, GraphedStep
+    from oracle.weights import formula_state_dict
+    D, B, G, N = 4, 2, 3, 512
+    opt = SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                          sample_num_level2=64, INPUT_FEATURE_NUM=D, Num_Class=512, batchSize=B, pooling="concatenation",
+                          SAMPLE_NUM=N)
+    torch.manual_seed(0)
+    clips = [torch.rand(B, G, N, D, device=DEV) - 0.5 for _ in range(3)]
+    orders = [np.array([1, 2, 0]), np.array([2, 0, 1]), np.array([0, 2, 1])]
+
+    def make():
+        net = PointNet_Plus(opt, gost=G)
+        net.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(D).items()})
+        net = net.to(DEV).train()
+        optim = torch.optim.Adam(net.parameters(), lr=3e-4, betas=(0.5, 0.999), eps=1e-6, capturable=True)
+        return net, ContrastiveStep(net, optim, opt, G)
+
+    net_e, step_e = make()
+    eager = [float(step_e(c, order=o)[0]) for c, o in zip(clips, orders)]
+    net_g, step_g = make()
+    g = GraphedStep(step_g, clips[0], G)                     # capture runs warm-up steps: reset the state afterwards
+    net_g.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(D).items()})
+    for st in step_g.optimizer.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    graphed = [float(g(c, order=o)[0]) for c, o in zip(clips, orders)]
+    print(eager, graphed)
+    np.testing.assert_allclose(graphed, eager, rtol=2e-5)

@@ -59,30 +59,37 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             key[j] = (i < N) ? __float_as_uint(dist2_exact(xs[i], ys[i], zs[i], cx, cy, cz)) : 0x7F800000u;
         }
 
-        // radix select: T = K-th smallest key (keys are bit patterns of non-negative floats)
-        uint32_t prefix = 0;
-        int remaining = K;
-        for (int bit = 30; bit >= 0; --bit) {
-            const uint32_t hi = ~((2u << bit) - 1u);            // bits above `bit`
+        // radix select on the float bit patterns (non-negative floats order like their bits), MSB first.
+        // Invariant: `cand` keys share the resolved prefix, `remaining` of them belong to the K smallest.
+        // Early exit as soon as cand == remaining (all candidates are kept): on continuous data the candidate
+        // set shrinks to `remaining` after ~log2(N) mantissa bits, i.e. roughly half of the 31 rounds.
+        uint32_t prefix = 0, hi = 0;
+        int remaining = K, cand = NPL * 64;                     // padding keys (+inf) are ordinary candidates
+        for (int bit = 30; bit >= 0 && cand != remaining; --bit) {
+            hi = ~((2u << bit) - 1u);                           // bits above `bit`
             const uint32_t sel = hi | (1u << bit);
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) cnt += ((key[j] & sel) == prefix) ? 1 : 0;
             const int total = wave_sum_i32(cnt);                // candidates whose `bit` is 0
-            if (total < remaining) { prefix |= (1u << bit); remaining -= total; }
+            if (total < remaining) { prefix |= (1u << bit); remaining -= total; cand -= total; }
+            else cand = total;
+            hi = sel;                                           // `bit` is resolved now
         }
-        const uint32_t T = prefix;                              // remaining = how many keys == T to keep
+        // keys with (key & hi) < prefix are kept; of those equal to prefix under `hi`, the first `remaining`
+        // in index order (all of them when the loop exited early; exact-tie rule otherwise)
 
         const size_t grp = (size_t)m * S + c;
         int base = 0, eq_taken = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane;
-            const bool is_eq = key[j] == T;
+            const uint32_t kh = key[j] & hi;
+            const bool is_eq = kh == prefix;
             const unsigned long long eqm = __ballot(is_eq);
             const int eq_rank = eq_taken + __popcll(eqm & lt);
             eq_taken += __popcll(eqm);
-            const bool take = (key[j] < T) || (is_eq && eq_rank < remaining);
+            const bool take = (kh < prefix) || (is_eq && eq_rank < remaining);
             const unsigned long long tm = __ballot(take);
             if (take) {
                 const int pos = base + __popcll(tm & lt);

@@ -16,6 +16,7 @@
 // conflict-free ds_read_b32; register prefetch of the next k-tile overlaps the 64 MFMAs of the current one.
 // Roofline: MFMA fp32 (157.3 TFLOP/s); 2*MI*NJ*KK FLOP per call.
 #include "common.h"
+#include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
 
@@ -93,6 +94,64 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
                 v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
             }
             *reinterpret_cast<float4*>(&T[il * LDK + k]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int i0, int j0,
+                                              int wave, int lane) {
+    const int h = lane >> 5, q = lane & 31, wr = wave >> 1, wc = wave & 1;
+    // ---- epilogue.  The accumulators hold (lane = column, register = row): column statistics are in-lane sums;
+    // the tile itself is transposed through LDS (the staging buffers are free now) so that it leaves as
+    // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound).
+    constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
+    float* Cz = g.C + (size_t)blockIdx.z * g.MI * g.ldc;
+    float* stg = smem + wave * (WR * SP);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + WC * wc + 32 * b + q;
+        const bool jin = j < g.NJ;
+        const float bias = (g.bias && jin) ? g.bias[j] : 0.f;
+        float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
+        if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
+        float s = 0.f, sq = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = 32 * a + rowmap(r, h);
+                const int i = i0 + WR * wr + il;
+                float v = acc[a][b][r] + bias;
+                if (g.xa && i < g.MI)
+                    v = fmaf(g.xa[(size_t)i * 3], xb0, fmaf(g.xa[(size_t)i * 3 + 1], xb1, fmaf(g.xa[(size_t)i * 3 + 2], xb2, v)));
+                stg[il * SP + 32 * b + q] = v;
+                if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
+            }
+        if (g.part) {
+            const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+            if (h == 0 && jin) {
+                double* pr = g.part + ((size_t)(blockIdx.y * 2 + wr) * g.NJ + j) * 2;
+                pr[0] = (double)st; pr[1] = (double)sqt;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // same-wave LDS hand-off (lanes swap roles)
+    const int jw = j0 + WC * wc;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + WC <= g.NJ);
+    constexpr int LPR = WC / 4;                                            // lanes per row (float4 each)
+#pragma unroll
+    for (int t = 0; t < WR * LPR / 64; ++t) {
+        const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
+        const int i = i0 + WR * wr + il;
+        if (i >= g.MI) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
+        if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
+        else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
         }
     }
 }
@@ -179,58 +238,122 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         cur ^= 1;
     }
 
-    // ---- epilogue.  The accumulators hold (lane = column, register = row): column statistics are in-lane sums;
-    // the tile itself is transposed through LDS (the staging buffers are free now) so that it leaves as
-    // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound).
-    constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
-    float* Cz = g.C + (size_t)blockIdx.z * g.MI * g.ldc;
-    float* stg = smem + wave * (WR * SP);
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write
+// instructions, no vmcnt wait in front of an LDS store).  The DMA destination is lane-linear (wave-uniform base +
+// lane*16 B), so the LDS images are UNPADDED and the bank-conflict swizzle lives on the SOURCE address:
+//   KC tile [idx][32 floats]: 8 lanes per 128-B row; the 16-B piece that lands in physical quad c' of row r is
+//        logical quad c' ^ ((r>>1)&7); the b128 fragment read of logical quad c uses physical c ^ ((r>>1)&7)
+//        (conflict-free for the ds_read_b128 lane groups of gfx950: checked by enumeration in DESIGN.md);
+//   IC tile [k][64T floats]: rows are already read along idx with b32 -> no swizzle.
+// Out-of-range rows / k read a 16-byte zero word instead (the source address is per lane).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int LAY, int T>
+__device__ __forceinline__ void dma_tile(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                         float* lds_tile, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (LAY == KC) {                 // pass i: rows 32i + 8w + (lane>>3), physical quad lane&7
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + WC * wc + 32 * b + q;
-        const bool jin = j < g.NJ;
-        const float bias = (g.bias && jin) ? g.bias[j] : 0.f;
-        float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
-        if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
-        float s = 0.f, sq = 0.f;
+        for (int i = 0; i < 2 * T; ++i) {
+            const int r = 32 * i + 8 * wave + (lane >> 3);
+            const int cq = (lane & 7) ^ ((r >> 1) & 7);
+            const int idx = idx0 + r, k = k0 + 4 * cq;
+            const float* src = (idx < nidx && k < kend) ? P + (size_t)idx * ld + k : g_zero16;
+            float* dst = lds_tile + (32 * i + 8 * wave) * 32;          // wave-uniform; lane*16 B is implicit
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    } else {                         // [k][64T]: one wave-instruction = 256 floats = 4/T k-rows... (64T floats per row)
+        constexpr int RPI = 256 / (64 * T);          // k-rows per wave-instruction (2 for T=2, 4 for T=1)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = 32 * a + rowmap(r, h);
-                const int i = i0 + WR * wr + il;
-                float v = acc[a][b][r] + bias;
-                if (g.xa && i < g.MI)
-                    v = fmaf(g.xa[(size_t)i * 3], xb0, fmaf(g.xa[(size_t)i * 3 + 1], xb1, fmaf(g.xa[(size_t)i * 3 + 2], xb2, v)));
-                stg[il * SP + 32 * b + q] = v;
-                if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
-            }
-        if (g.part) {
-            const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
-            if (h == 0 && jin) {
-                double* pr = g.part + ((size_t)(blockIdx.y * 2 + wr) * g.NJ + j) * 2;
-                pr[0] = (double)st; pr[1] = (double)sqt;
-            }
+        for (int i = 0; i < 2 * T; ++i) {
+            const int krow = RPI * (4 * i + wave) + lane / (16 * T);
+            const int idx = idx0 + 4 * (lane % (16 * T)), k = k0 + krow;
+            const float* src = (idx < nidx && k < kend) ? P + (size_t)k * ld + idx : g_zero16;
+            float* dst = lds_tile + RPI * (4 * i + wave) * (64 * T);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // same-wave LDS hand-off (lanes swap roles)
-    const int jw = j0 + WC * wc;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + WC <= g.NJ);
-    constexpr int LPR = WC / 4;                                            // lanes per row (float4 each)
+}
+
+template <int LA, int LB, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm_dma(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AF = BM * BK, BF = BN * BK;                          // unpadded images
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);
+    constexpr int SMEM = (2 * (AF + BF) > STG) ? 2 * (AF + BF) : STG;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const sA0 = smem;
+    float* const sB0 = smem + 2 * AF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int t = 0; t < WR * LPR / 64; ++t) {
-        const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
-        const int i = i0 + WR * wr + il;
-        if (i >= g.MI) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
-        if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
-        else {
-            const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    dma_tile<LA, TM>(g.A, g.lda, i0, g.MI, kbeg, kend, sA0, tid);
+    dma_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, kbeg, kend, sB0, tid);
+    __syncthreads();                                                   // drains the DMAs (vmcnt(0)) + barrier
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (k0 + BK < kend) {
+            dma_tile<LA, TM>(g.A, g.lda, i0, g.MI, k0 + BK, kend, sA0 + (cur ^ 1) * AF, tid);
+            dma_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, k0 + BK, kend, sB0 + (cur ^ 1) * BF, tid);
         }
+        const float* pa = sA0 + cur * AF;
+        const float* pb = sB0 + cur * BF;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float av[TM][4], bv[TN][4];
+            if (LA == KC) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int r = 32 * TM * wr + 32 * a + q;
+                    const float4 u = *reinterpret_cast<const float4*>(&pa[r * 32 + 4 * ((4 * h + s4) ^ ((r >> 1) & 7))]);
+                    av[a][0] = u.x; av[a][1] = u.y; av[a][2] = u.z; av[a][3] = u.w;
+                }
+            }
+            if (LB == KC) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int r = 32 * TN * wc + 32 * b + q;
+                    const float4 u = *reinterpret_cast<const float4*>(&pb[r * 32 + 4 * ((4 * h + s4) ^ ((r >> 1) & 7))]);
+                    bv[b][0] = u.x; bv[b][1] = u.y; bv[b][2] = u.z; bv[b][3] = u.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (LA == IC) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) av[a][e] = pa[(16 * h + 4 * s4 + e) * BM + 32 * TM * wr + 32 * a + q];
+                }
+                if (LB == IC) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bv[b][e] = pb[(16 * h + 4 * s4 + e) * BN + 32 * TN * wc + 32 * b + q];
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(av[a][e], bv[b][e], acc[a][b]);
+            }
+        }
+        __syncthreads();                                               // next tile landed, this one free
+        cur ^= 1;
     }
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane);
 }
 
 // sum over split-K slices: out[e] = sum_z part[z][e]
@@ -251,13 +374,22 @@ __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n
 template <int LA, int LB, bool PRO>
 int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     const long long big = (long long)((g.NJ + 127) / 128) * ((g.MI + 127) / 128) * nz;
+    static const int use_dma = getenv("FACL_GEMM_DMA") ? atoi(getenv("FACL_GEMM_DMA")) : 1;
+    // LDS-DMA needs 16-byte aligned 4-element pieces: leading dimensions and extents multiples of 4
+    // Measured A/B in one process (49152-row layers): the DMA path wins when BOTH operands are idx-contiguous
+    // (wgrad: 0.431 vs 0.538 ms at 1024x512) and loses a few % when a k-contiguous operand needs the
+    // source-side swizzle (forward 0.564 vs 0.552, dgrad 0.475 vs 0.460) -> used for wgrad only.
+    const bool dma_ok = use_dma && !PRO && LA == IC && LB == IC && !(g.lda & 3) && !(g.ldb & 3) && !(g.MI & 3) &&
+                        !(g.NJ & 3) && !(((uintptr_t)g.A | (uintptr_t)g.B) & 15);
     if (big >= 256) {
         dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
-        hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
+        if (dma_ok) hipLaunchKernelGGL((k_gemm_dma<LA, LB, 2, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
         if (rows_per_part) *rows_per_part = 64;
     } else {
         dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
-        hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
+        if (dma_ok) hipLaunchKernelGGL((k_gemm_dma<LA, LB, 1, 1>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
         if (rows_per_part) *rows_per_part = 32;
     }
     return facl_launch_status();

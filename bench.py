@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--D", type=int, default=3, help="input channels (north_star: 3-ch; checkpoints: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (single GPU only)")
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--N", type=int, default=2048)
     ap.add_argument("--D", type=int, default=3, help="input channels (north_star: 3-ch; checkpoints: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fps", type=int, default=0, help="1: FPS-reorder the views on the GPU inside the timed step")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (single GPU only)")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -141,7 +142,7 @@ def main():
     net.bn_reduce_fn = fdist.make_bn_reduce_fn()
     use_graph = bool(a.graph) and world == 1
     optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, capturable=use_graph)
-    step = ContrastiveStep(net, optim, opt, a.T)
+    step = ContrastiveStep(net, optim, opt, a.T, fps_reorder=bool(a.fps))
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]   # resident in HBM

@@ -23,6 +23,17 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(out_path, csrc_dir, verbose=False):
+    """Build an experimental library from another source directory (A/B timing in one process)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = sorted(glob.glob(os.path.join(csrc_dir, "*.hip")))
+    cmd = [hipcc] + FLAGS + ["-o", out_path] + srcs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout.decode(errors="replace"))
+    return out_path
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT

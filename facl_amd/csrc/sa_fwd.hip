@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, 
 // fwd2: transposed orientation  D2^T[c2][p] = sum_k W2[c2][k] a1[p][k]  so that the result
 // registers are (lane = position, register = channel) = the fragment layout.
 template <int D>
-__global__ __launch_bounds__(256) void k_sa_fwd2(const float* __restrict__ x, int nunits,
+__global__ __launch_bounds__(256, 2) void k_sa_fwd2(const float* __restrict__ x, int nunits,
                                                  const float* __restrict__ l1tab_g, const float* __restrict__ W2,
                                                  const float* __restrict__ b2, float* __restrict__ y2f,
                                                  double* __restrict__ part) {
@@ -344,7 +344,7 @@ extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* 
     if (!x || !l1tab || !W2 || !b2 || !y2f || (sums2 && !ws)) return FACL_E_NULL;
     if ((D != 3 && D != 4) || nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
+    const int grid = (int)(nunits < 2 * SA_GRID * 4 ? (nunits + 3) / 4 : 2 * SA_GRID);   // 2 workgroups per CU
     double* part = sums2 ? (double*)ws : nullptr;
     if (D == 4) hipLaunchKernelGGL((k_sa_fwd2<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
     else hipLaunchKernelGGL((k_sa_fwd2<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);

@@ -59,6 +59,9 @@ def build_parser(default_branch):
     p.add_argument('--group_radius', type=float, default=None,
                    help='NEW: r^2 of the grouper (default: the reference literals 0.06 at N=512, 0.16 otherwise)')
     p.add_argument('--log_file', type=str, default='', help='NEW: log path (reference: ../ntu/ntu60_new2/30_0425.log)')
+    p.add_argument('--fps_reorder', type=int, default=0,
+                   help='NEW: 1 = FPS-reorder every view on the GPU before grouping (cn3D_data_set.py:665-672; the '
+                        'reference assumes FPS-ordered clouds but its live loader never calls it)')
     return p
 
 
@@ -70,9 +73,10 @@ def synthetic_batch(B, G, N, D, device, generator=None):
 class ContrastiveStep:
     """One training iteration = the loop body of cn3d_train_motion_GL.py:224-335."""
 
-    def __init__(self, netR, optimizer, opt, num_crop, group_radius=None):
+    def __init__(self, netR, optimizer, opt, num_crop, group_radius=None, fps_reorder=False):
         self.netR, self.optimizer, self.opt, self.G = netR, optimizer, opt, num_crop
         self.r2 = group_radius
+        self.fps_reorder = fps_reorder
         self.rank = torch.distributed.get_rank() if fdist.is_distributed() else 0
 
     def group(self, data1):
@@ -98,6 +102,10 @@ class ContrastiveStep:
         netR, G = self.netR, self.G
         B, G_, N, D = out_points.shape
         data1 = out_points.permute(1, 0, 2, 3).reshape(-1, N, D).float()          # :226-228 (view-major rows)
+        if self.fps_reorder:                                                       # FPS picks first (start index 0)
+            from .fps import fps_sample_data
+            data1 = fps_sample_data(data1, self.opt.sample_num_level1,
+                                    torch.zeros(data1.shape[0], dtype=torch.int32, device=data1.device))
         xt, yt = self.group(data1)
         x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
         x_keys = fdist.all_gather_view_major(x, G)
@@ -176,7 +184,7 @@ def run(default_branch, ckpt_pattern, args=None):
     netR = MODELL.PointNet_Plus(opt, gost=num_crop).to(device)
     netR.bn_reduce_fn = fdist.make_bn_reduce_fn()
     optimizer = torch.optim.Adam(netR.parameters(), lr=opt.learning_rate, betas=(0.5, 0.999), eps=1e-06)
-    step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius)
+    step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius, bool(opt.fps_reorder))
     gen = torch.Generator(device=device)
     gen.manual_seed(1000 + rank)
 

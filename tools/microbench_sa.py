@@ -29,8 +29,17 @@ def main():
     ap.add_argument("--M", type=int, default=768)
     ap.add_argument("--D", type=int, default=3)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--ab", type=str, default="", help="second libfacl_hip build: A/B both in THIS process, interleaved")
     a = ap.parse_args()
     lib = _lib.load_library()
+    lib_b = None
+    if a.ab:
+        import ctypes
+        lib_b = ctypes.CDLL(os.path.abspath(a.ab))
+        for name, argtypes in _lib.SIGNATURES.items():
+            fn = getattr(lib_b, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_longlong if name in _lib.RESTYPE_I64 else ctypes.c_int
     dev = torch.device("cuda:0")
     nunits, D = a.M * 64, a.D
     P = nunits * 64
@@ -57,21 +66,34 @@ def main():
     st = _lib.stream()
     p = _lib.ptr
     F = 2.0 * 64 * 64 * P          # flops of one 64x64 layer over all positions
-    kernels = {
+    def make(lib):
+      return {
         "fwd2": (lambda: lib.facl_sa_fwd2(p(x), nunits, D, p(l1tab), p(W2), p(b2), p(dz2f), p(s64), p(ws), st), F),
         "fwd3": (lambda: lib.facl_sa_fwd3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), st), 4 * F),
         "bwd0": (lambda: lib.facl_sa_bwd0(p(coef), p(ymax), nunits, p(bnc3), p(coef), p(s256), p(ws), st), 0),
         "bwd1": (lambda: lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg), p(dz2f), p(s64), p(ws), st), F),
         "bwd_w3": (lambda: lib.facl_sa_bwd_w3(p(y2f), nunits, p(bnc2), p(coef), p(arg), p(o3), p(ws), st), 0.75 * F),
         "bwd2": (lambda: lib.facl_sa_bwd2(p(dz2f), p(y2f), p(x), nunits, D, p(bw2), p(W2), p(l1tab), p(o2), p(ws), st), 2.5 * F),
-    }
+      }
+    kernels = make(lib)
+    kernels_b = make(lib_b) if lib_b is not None else None
     for name, (fn, fl) in kernels.items():
         if a.only and name not in a.only.split(","):
             continue
         rc = fn()
         assert rc == 0, (name, rc)
-        ms = timeit(fn)
-        print(f"{name:7s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TFLOP/s (MFMA work only)")
+        if kernels_b is None:
+            ms = timeit(fn)
+            print(f"{name:7s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TFLOP/s (MFMA work only)")
+        else:
+            fb = kernels_b[name][0]
+            assert fb() == 0
+            ta, tb = [], []
+            for _ in range(5):                      # interleaved rounds in one process (guide rule 24)
+                ta.append(timeit(fn, iters=6, warmup=1))
+                tb.append(timeit(fb, iters=6, warmup=1))
+            ta.sort(); tb.sort()
+            print(f"{name:7s} A(base) median {ta[2]:.3f} min {ta[0]:.3f} ms | B(exp) median {tb[2]:.3f} min {tb[0]:.3f} ms | B/A {tb[2]/ta[2]:.3f}")
 
 
 if __name__ == "__main__":

@@ -141,9 +141,6 @@ class PointNet_Plus(nn.Module):
             raise RuntimeError("input has %d channels, model was built for %d" % (D, self.INPUT_FEATURE_NUM))
         if K != self._pool_K:
             raise RuntimeError("pooling window is %d neighbours, got K=%d" % (self._pool_K, K))
-        if K != sa_mlp.UNIT:
-            raise NotImplementedError("the HIP set-abstraction kernels are built for knn_K = 64 (one 64-position unit per "
-                                      "group); K=%d is not implemented yet" % K)
         if S != self._pool_S:
             raise RuntimeError("model pools over %d centroids, got S=%d" % (self._pool_S, S))
         if M % self.gost:
@@ -154,7 +151,7 @@ class PointNet_Plus(nn.Module):
         training = self.training
 
         params, buffers = self._sa_args()
-        state = dict(training=training, buffers=buffers, reduce_fn=self.bn_reduce_fn)
+        state = dict(training=training, buffers=buffers, reduce_fn=self.bn_reduce_fn, K=K)
         pooled = sa_mlp.SAMLPFunction.apply(x_rows, state, *params)           # (M*S,256)   net3DV_1 (:218)
         if training:
             for i in (1, 4, 7):

@@ -45,13 +45,40 @@ def _bn_eval(C, gamma, beta, running_mean, running_var):
     return bnc
 
 
-def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
-    """x_rows (P,D) contiguous fp32 (P = groups*64).  ``p``: dict with W1,b1,g1,be1,rm1,rv1, ...3.
-    Returns (pooled (P/64,256), ctx) where ctx carries what the backward needs.
-    ``reduce_fn(t)`` (optional) all-reduces an fp64 tensor in place (SyncBN); counts are then the
-    global ones: ``reduce_fn`` must also be applied to the count, handled here."""
+def _running_update(bnc, rm, rv, n_true):
+    """Running-statistics update with an explicit element count (used when positions are replicated: the batch
+    mean / biased variance are unaffected by uniform replication, the unbiased factor n/(n-1) is not)."""
+    mean = bnc[0]
+    var = 1.0 / (bnc[1].double() ** 2) - BN_EPS
+    unb = (var * (n_true / max(n_true - 1.0, 1.0))).float()
+    rm.mul_(1 - BN_MOMENTUM).add_(mean, alpha=BN_MOMENTUM)
+    rv.mul_(1 - BN_MOMENTUM).add_(unb, alpha=BN_MOMENTUM)
+
+
+def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=64):
+    """x_rows (P,D) contiguous fp32, P = groups*K rows.  ``p``: dict with W1,b1,g1,be1,rm1,rv1, ...3.
+    Returns (pooled (groups,256), ctx) where ctx carries what the backward needs.
+    ``reduce_fn(t)`` (optional) all-reduces an fp64 tensor in place (SyncBN).
+
+    The kernels work on units of 64 positions.  K = 64 (the reference's live value, utils_my.py:260) maps one
+    group to one unit.  Other K are served around the same kernels (cold path, tensor glue):
+      * K = 64*R: a group spans R units; their per-unit maxima are merged before the pooling step and the
+        sparse backward values are routed to the winning unit;
+      * K | 64: every group is replicated 64/K times inside its unit.  Uniform replication leaves the batch mean,
+        the biased variance, the max and (with P' = replicated count used consistently) every gradient unchanged;
+        only the unbiased running-variance factor needs the true count."""
     lib = _lib.load_library()
     _lib.require_cuda(x_rows)
+    rep, R = 1, 1
+    if K != UNIT:
+        if K > UNIT and K % UNIT == 0:
+            R = K // UNIT
+        elif 0 < K < UNIT and UNIT % K == 0:
+            rep = UNIT // K
+            G_, D_ = x_rows.shape[0] // K, x_rows.shape[1]
+            x_rows = x_rows.view(G_, K, D_).repeat(1, rep, 1).reshape(G_ * UNIT, D_).contiguous()
+        else:
+            raise NotImplementedError("knn_K must divide 64 or be a multiple of 64 (got %d)" % K)
     P, D = x_rows.shape
     if P % UNIT:
         raise ValueError("P must be a multiple of 64 (knn_K = 64)")
@@ -77,8 +104,12 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
         sums1 = torch.empty((64, 2), **f64)
         _lib.check(lib.facl_bn1_sums_from_moments(_lib.ptr(mom), count, D, _lib.ptr(W1), _lib.ptr(p["b1"]),
                                                   _lib.ptr(sums1), st), "facl_bn1_sums_from_moments")
-        rm, rv = (p["rm1"], p["rv1"]) if update_running else (None, None)
+        direct = update_running and rep == 1
+        n_true = count / rep
+        rm, rv = (p["rm1"], p["rv1"]) if direct else (None, None)
         bnc1 = _bn_finalize(sums1, 64, count, p["g1"], p["be1"], rm, rv)
+        if update_running and not direct:
+            _running_update(bnc1, p["rm1"], p["rv1"], n_true)
         ctx["mom"] = mom
     else:
         bnc1 = _bn_eval(64, p["g1"], p["be1"], p["rm1"], p["rv1"])
@@ -92,8 +123,10 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
     if training:
         if reduce_fn is not None:
             reduce_fn(sums2)
-        rm, rv = (p["rm2"], p["rv2"]) if update_running else (None, None)
+        rm, rv = (p["rm2"], p["rv2"]) if direct else (None, None)
         bnc2 = _bn_finalize(sums2, 64, count, p["g2"], p["be2"], rm, rv)
+        if update_running and not direct:
+            _running_update(bnc2, p["rm2"], p["rv2"], n_true)
     else:
         bnc2 = _bn_eval(64, p["g2"], p["be2"], p["rm2"], p["rv2"])
     sgn3 = torch.where(p["g3"] < 0, -1.0, 1.0).to(torch.float32)
@@ -108,19 +141,31 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True):
             reduce_fn(sums3)
         # statistics were taken of sgn3*y3: flip the channel sums back (sum of squares is unchanged)
         sums3[:, 0] *= sgn3.double()
-        rm, rv = (p["rm3"], p["rv3"]) if update_running else (None, None)
+        rm, rv = (p["rm3"], p["rv3"]) if direct else (None, None)
         bnc3 = _bn_finalize(sums3, 256, count, p["g3"], p["be3"], rm, rv)
+        if update_running and not direct:
+            _running_update(bnc3, p["rm3"], p["rv3"], n_true)
     else:
         bnc3 = _bn_eval(256, p["g3"], p["be3"], p["rm3"], p["rv3"])
-    pooled = torch.empty((nunits, 256), dtype=torch.float32, device=dev)
-    _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), nunits, 256, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(pooled), st),
+    ngroups, ymax_g, rsel = nunits, ymax, None
+    if R > 1:                                    # a group spans R units: merge their maxima (first unit wins ties)
+        ngroups = nunits // R
+        ymax_g, rsel = ymax.view(ngroups, R, 256).max(dim=1)
+        ymax_g = ymax_g.contiguous()
+    pooled = torch.empty((ngroups, 256), dtype=torch.float32, device=dev)
+    _lib.check(lib.facl_sa_pool(_lib.ptr(ymax_g), ngroups, 256, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(pooled), st),
                "facl_sa_pool")
-    ctx.update(y2f=y2f, ymax=ymax, arg=arg, bnc1=bnc1, bnc2=bnc2, bnc3=bnc3, sgn3=sgn3, l1tab=l1tab, count=count,
-               nunits=nunits, D=D)
+    ctx.update(y2f=y2f, ymax=ymax_g, arg=arg, bnc1=bnc1, bnc2=bnc2, bnc3=bnc3, sgn3=sgn3, l1tab=l1tab, count=count,
+               nunits=nunits, D=D, R=R, rsel=rsel, ngroups=ngroups, x_rows=x_rows)
     return pooled, ctx
 
 
 def sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
+    x_rows = ctx["x_rows"]                       # the (possibly replicated) rows the forward actually ran on
+    return _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn)
+
+
+def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     """Gradients of the 12 parameters of net3DV_1 given dL/dpooled (P/64,256).
 
     Four heavy passes (csrc/sa_bwd.hip) with three fp64 closed-form assembly kernels between them
@@ -141,10 +186,15 @@ def sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     ptr = _lib.ptr
 
     # ---- pass 0: sparse values + (dbeta3, dgamma3)
-    coef = torch.empty((nunits, 256), **f32)
+    ngroups, R = ctx["ngroups"], ctx["R"]
+    coef = torch.empty((ngroups, 256), **f32)
     sums0 = torch.empty((256, 2), **f64)
-    _lib.check(lib.facl_sa_bwd0(ptr(dpooled), ptr(ctx["ymax"]), nunits, ptr(bnc3), ptr(coef), ptr(sums0), ptr(ws), st),
+    _lib.check(lib.facl_sa_bwd0(ptr(dpooled), ptr(ctx["ymax"]), ngroups, ptr(bnc3), ptr(coef), ptr(sums0), ptr(ws), st),
                "facl_sa_bwd0")
+    if R > 1:                                    # route each group's sparse value to the unit that won the max
+        cu = torch.zeros((ngroups, R, 256), **f32)
+        cu.scatter_(1, ctx["rsel"].unsqueeze(1), coef.unsqueeze(1))
+        coef = cu.view(nunits, 256)
     sums0_l = sums0
     if reduce_fn is not None:
         sums0 = reduce_fn(sums0.clone())
@@ -199,7 +249,7 @@ class SAMLPFunction(torch.autograd.Function):
     def forward(ctx, x_rows, state, *params):
         p = dict(zip(_PARAM_ORDER, [t.detach().contiguous() for t in params]))
         p.update(state["buffers"])
-        pooled, c = sa_mlp_forward(x_rows, p, state["training"], state.get("reduce_fn"))
+        pooled, c = sa_mlp_forward(x_rows, p, state["training"], state.get("reduce_fn"), K=state.get("K", UNIT))
         ctx.c, ctx.p, ctx.x_rows, ctx.reduce_fn = c, p, x_rows, state.get("reduce_fn")
         ctx.training = state["training"]
         return pooled

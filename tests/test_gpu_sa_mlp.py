@@ -124,3 +124,48 @@ def test_sa_backward_vs_oracle_fp64(D, neg):
         print(f"{k}: mine-vs-fp64 {e_mine:.2e}  torch-fp32-vs-fp64 {e_t32:.2e}")
         assert e_mine < 1e-4, k
         assert e_mine < 3 * e_t32 + 1e-5, k
+
+
+@pytest.mark.parametrize("S,K", [(32, 128), (16, 32), (16, 8)])
+def test_sa_other_K_kernel_level(S, K):
+    """net3DV_1 alone for K = 64*R and K | 64, fixed upstream gradient: pooled output, all parameter gradients and the
+    running statistics vs the fp64 oracle (no tie-flip noise: the upstream gradient does not depend on the forward)."""
+    from facl_amd import sa_mlp, utils_my
+    from oracle import encoder as E
+    from oracle.weights import formula_state_dict
+    D, M, N = 4, 5, 512
+    torch.manual_seed(S + K)
+    pts = (torch.rand(M, N, D) - 0.5)
+    xt, yt = utils_my.knn_radius_group(pts.to(DEV), S, K, 0.1)
+    sd = formula_state_dict(D)
+    p = _params(sd, DEV)
+    x_rows = xt.permute(0, 2, 3, 1).reshape(-1, D)
+    names = sa_mlp._PARAM_ORDER
+    params = [p[k].clone().requires_grad_(True) for k in names]
+    state = dict(training=True, K=K, buffers={k: p[k] for k in ("rm1", "rv1", "rm2", "rv2", "rm3", "rv3")})
+    pooled = sa_mlp.SAMLPFunction.apply(x_rows, state, *params)
+    assert pooled.shape == (M * S, 256)
+    up = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    (pooled * up).sum().backward()
+    sdr = {k: (torch.as_tensor(v).double() if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
+           for k, v in sd.items()}
+    keys = [k for k in sdr if k.startswith("net3DV_1") and "running" not in k and "num_batches" not in k]
+    for k in keys:
+        sdr[k].requires_grad_(True)
+    h = xt.cpu().double()
+    for li in (0, 3, 6):
+        h = E._conv_bn_relu(sdr, "net3DV_1", li, h, True)
+    pl = F.max_pool2d(h, (1, K), stride=1).squeeze(-1).permute(0, 2, 1).reshape(-1, 256)
+    (pl * up.cpu().double()).sum().backward()
+    assert max_rel_rows(pooled.detach().cpu().numpy(), pl.detach().numpy()) < 2e-5
+    keymap = {"W1": "net3DV_1.0.weight", "g1": "net3DV_1.1.weight", "be1": "net3DV_1.1.bias",
+              "W2": "net3DV_1.3.weight", "g2": "net3DV_1.4.weight", "be2": "net3DV_1.4.bias",
+              "W3": "net3DV_1.6.weight", "g3": "net3DV_1.7.weight", "be3": "net3DV_1.7.bias"}
+    for k, prm in zip(names, params):
+        if k not in keymap:
+            continue
+        r64 = sdr[keymap[k]].grad.numpy()
+        assert rel_err(prm.grad.cpu().numpy().reshape(r64.shape), r64) < 2e-5, k
+    for i, li in ((1, 1), (2, 4), (3, 7)):
+        for nm, key in (("rm", "running_mean"), ("rv", "running_var")):
+            assert rel_err(p[f"{nm}{i}"].cpu().numpy(), sdr[f"net3DV_1.{li}.{key}"].numpy()) < 2e-6, (nm, i)

@@ -84,3 +84,21 @@ def test_graph_replay_equals_eager():
     graphed = [float(g(c, order=o)[0]) for c, o in zip(clips, orders)]
     print(eager, graphed)
     np.testing.assert_allclose(graphed, eager, rtol=2e-5)
+
+
+def test_linear_probe_consumes_extracted_feature_format():
+    """(f)-2: the probe trains on vectors in the extraction format (motion ++ appearance, 22*512) and separates
+    classes that differ in the features; state_dict keys match the reference's Final_FC."""
+    from facl_amd import linear_classify as LC
+    torch.manual_seed(0)
+    n, C = 512, 8
+    labels = torch.randint(0, C, (n,), device=DEV)
+    protos = torch.randn(C, 22 * 512, device=DEV)
+    feats = protos[labels] + 0.5 * torch.randn(n, 22 * 512, device=DEV)
+    model, top1 = LC.fit(feats, labels, num_class=120, nepoch=6, batch=128, lr=3e-3)
+    assert list(model.state_dict().keys()) == ["fc.weight", "fc.bias"]
+    assert tuple(model.fc.weight.shape) == (120, 22 * 512)
+    assert top1 > 90.0, top1
+    ref = torch.nn.functional.linear(torch.nn.functional.normalize(feats[:7].double(), dim=1), model.fc.weight.double(),
+                                     model.fc.bias.double())
+    assert torch.allclose(model(feats[:7]).double(), ref, rtol=1e-4, atol=1e-5)

@@ -67,10 +67,13 @@ class _AllGatherViewMajor(torch.autograd.Function):
         G, R, r, Bl, C, group = ctx.meta
         if dist.get_backend(group) == "nccl":
             # reduce-scatter: each rank only needs the sum of ITS rows (1/R of the all-reduce traffic)
-            gin = g.view(G, R, Bl, C).permute(1, 0, 2, 3).contiguous()          # (R, G, Bl, C): rank-major chunks
-            out = torch.empty((G, Bl, C), dtype=g.dtype, device=g.device)
-            dist.reduce_scatter_tensor(out, gin, op=dist.ReduceOp.SUM, group=group)
-            return out.reshape(G * Bl, C), None, None
+            try:
+                gin = g.view(G, R, Bl, C).permute(1, 0, 2, 3).contiguous()      # (R, G, Bl, C): rank-major chunks
+                out = torch.empty((G, Bl, C), dtype=g.dtype, device=g.device)
+                dist.reduce_scatter_tensor(out, gin, op=dist.ReduceOp.SUM, group=group)
+                return out.reshape(G * Bl, C), None, None
+            except (RuntimeError, AttributeError, ValueError):                  # argument validation: same on every rank
+                pass
         g = g.contiguous()                                                    # gloo (CPU rehearsal): no reduce-scatter
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
         return g.view(G, R, Bl, C)[:, r].reshape(G * Bl, C), None, None

@@ -59,7 +59,8 @@ RESTYPE_I64 = {"facl_ws_bytes"}
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfacl_hip.so")
+    # FACL_LIB: load another build of the same ABI (kernel experiments: A/B timing, parity of a candidate build)
+    return os.environ.get("FACL_LIB") or os.path.join(_HERE, "libfacl_hip.so")
 
 
 def load_library():

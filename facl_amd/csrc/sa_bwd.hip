@@ -19,6 +19,7 @@
 //                  R1 += [x|1]^T dz1   (everything layer 1 needs: dW1, dgamma1, dbeta1 follow in closed form)
 // Roofline: MFMA fp32 for bwd1/bwd2/bwd_w3 (128..320 MFMA 32x32x2 per 64 positions), HBM for bwd0.
 #include "common.h"
+#include "sa_bwd1_scatter.inc"
 #include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
@@ -111,28 +112,23 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
         const uchar4 ar4 = arn;
         const float cfv[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
         const int arv[4] = {ar4.x, ar4.y, ar4.z, ar4.w};
-        f32x32 srow0, srow1;
-#pragma unroll
-        for (int t = 0; t < 32; ++t) { srow0[t] = 0.f; srow1[t] = 0.f; }
-        for (int i = 0; i < 64; i += 2) {
-            float w[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) w[t] = w3n[(4 * i + t) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int src = i + (t >> 2);
-                const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfv[t & 3]), src));
-                const int ps = __builtin_amdgcn_readlane(arv[t & 3], src);
-                const float v = cf * w[t];
-                // branch-free: a uniform `if` makes the compiler copy the whole 32-register vector per element
-                const bool lo = ps < 32;
-                const int pi = ps & 31;
-                srow0[pi] += lo ? v : 0.f;
-                srow1[pi] += lo ? 0.f : v;
-            }
+        {
+            // 64 row accumulators in v192..v255, addressed by GPR indexing (SRC2+DST) inside ONE hand-written block:
+            // per element 2 v_readlane + s_set_gpr_idx_idx + v_fma (hipcc's own indexed RMW costs ~110 cycles per
+            // element because it toggles the index mode around separate read / add / write moves).
+            float w0, w1, w2, w3, x0, x1, x2, x3;
+            unsigned wa, si, szero, sm0, sc0, sc1, sc2, sc3, sp0, sp1, sp2, sp3;
+            const unsigned waddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(w3n + lane));   // LDS byte address
+            const unsigned taddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(T + lane));
+            asm volatile(FACL_SCATTER_ASM_TEXT
+                         : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [x0] "=&v"(x0), [x1] "=&v"(x1),
+                           [x2] "=&v"(x2), [x3] "=&v"(x3), [wa] "=&v"(wa), [i] "=&s"(si),
+                           [zero] "=&s"(szero), [m0s] "=&s"(sm0), [c0] "=&s"(sc0), [c1] "=&s"(sc1), [c2] "=&s"(sc2),
+                           [c3] "=&s"(sc3), [p0] "=&s"(sp0), [p1] "=&s"(sp1), [p2] "=&s"(sp2), [p3] "=&s"(sp3)
+                         : [cf0] "v"(cfv[0]), [cf1] "v"(cfv[1]), [cf2] "v"(cfv[2]), [cf3] "v"(cfv[3]), [ar0] "v"(arv[0]),
+                           [ar1] "v"(arv[1]), [ar2] "v"(arv[2]), [ar3] "v"(arv[3]), [waddr] "v"(waddr), [ta] "v"(taddr)
+                         : FACL_SCATTER_ASM_CLOBBERS);
         }
-#pragma unroll
-        for (int t = 0; t < 32; ++t) { T[t * TP + lane] = srow0[t]; T[(32 + t) * TP + lane] = srow1[t]; }
         WAVE_LDS_FENCE();      // other lanes read T below
         // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j]
         float yv[2][2][16];

@@ -18,7 +18,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
         glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -45,7 +45,8 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
+        hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+            glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [src] + hdrs)):
             continue

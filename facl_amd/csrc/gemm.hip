@@ -98,15 +98,30 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
     }
 }
 
+// XCD-aware tile order: workgroup b of the linearised grid is dispatched to XCD b % 8 (8 XCDs, one L2 each).  Remap so
+// that each XCD works through a CONTIGUOUS range of logical tiles: the column tiles that share an A row-panel (and
+// all tiles of one split-K slice) then hit the same L2 instead of pulling the panel through the fabric 8 times.
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile() {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int total = nbx * nby * gridDim.z;
+    const int b = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+    const int per = total >> 3, rem = total & 7, xcd = b & 7, slot = b >> 3;
+    const int L = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    TileId t;
+    t.x = L % nbx; t.y = (L / nbx) % nby; t.z = L / (nbx * nby);
+    return t;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int i0, int j0,
-                                              int wave, int lane) {
+                                              int wave, int lane, int by, int bz) {
     const int h = lane >> 5, q = lane & 31, wr = wave >> 1, wc = wave & 1;
     // ---- epilogue.  The accumulators hold (lane = column, register = row): column statistics are in-lane sums;
     // the tile itself is transposed through LDS (the staging buffers are free now) so that it leaves as
     // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound).
     constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
-    float* Cz = g.C + (size_t)blockIdx.z * g.MI * g.ldc;
+    float* Cz = g.C + (size_t)bz * g.MI * g.ldc;
     float* stg = smem + wave * (WR * SP);
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -131,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
         if (g.part) {
             const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
             if (h == 0 && jin) {
-                double* pr = g.part + ((size_t)(blockIdx.y * 2 + wr) * g.NJ + j) * 2;
+                double* pr = g.part + ((size_t)(by * 2 + wr) * g.NJ + j) * 2;
                 pr[0] = (double)st; pr[1] = (double)sqt;
             }
         }
@@ -167,8 +182,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     float* const sB0 = smem + 2 * AF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * BM, j0 = tile.x * BN;
+    const int kbeg = tile.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
 
     f32x16 acc[TM][TN];
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         cur ^= 1;
     }
 
-    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane);
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -292,8 +308,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(GemmArgs g) {
     float* const sB0 = smem + 2 * AF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * BM, j0 = tile.x * BN;
+    const int kbeg = tile.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
 
     f32x16 acc[TM][TN];
@@ -353,7 +370,228 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(GemmArgs g) {
         __syncthreads();                                               // next tile landed, this one free
         cur ^= 1;
     }
-    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane);
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-bf16 variant ("bf16x6"): the fp32 MFMA of gfx950 runs at 1/16 of the bf16 MFMA rate, so each fp32 operand
+// is split EXACTLY into three bf16 pieces while its tile is staged (x = hi + mid + lo, round-to-nearest at each
+// level: 3 x 8 mantissa bits + the sign trick cover the 24-bit significand) and the product is accumulated from the
+// six piece products whose magnitude reaches 2^-24 of |a||b|:
+//      a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh)   [+ am*bl + al*bm + al*bl  <= 2^-25 |a||b|, dropped]
+// Every bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result has
+// fp32-GEMM accuracy (tests/test_gpu_gemm.py compares both paths with an fp64 product) at 6/16 of the MFMA time.
+// LDS image per operand: [piece][idx][32 k + 8 pad] bf16 (80-B rows: the ds_read_b128 fragment reads and the
+// staging writes are conflict-free); both global layouts are transposed into it by the register staging pass.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr int SBROW = BK + 8;                  // bf16 elements per LDS row
+
+__device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
+    const f32x2v v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));       // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mi, unsigned& lo) {
+    hi = pk_bf16(x0, x1);
+    // scalar subtractions on purpose: the SLP vectoriser would fuse each pair into v_pk_add_f32, which costs far more
+    // than two v_sub_f32 beside MFMAs (MI355X guide, "packed f32 VALU ... an anti-lever beside MFMAs")
+    const float r0 = sub_f32(x0, __builtin_bit_cast(float, hi << 16)), r1 = sub_f32(x1, __builtin_bit_cast(float, hi & 0xffff0000u));
+    mi = pk_bf16(r0, r1);
+    const float s0 = sub_f32(r0, __builtin_bit_cast(float, mi << 16)), s1 = sub_f32(r1, __builtin_bit_cast(float, mi & 0xffff0000u));
+    lo = pk_bf16(s0, s1);
+}
+
+// Branch-free tile fetches for the split path (a tile whose loads sit in 2T if/else blocks defeats the scheduler):
+// addresses are CLAMPED into the operand (rows beyond nidx re-read the last row: they only feed output rows / columns
+// that the epilogue never stores or counts), and k beyond kend -- possible only in the last, partial stage of a
+// contraction that is not a multiple of 32 -- is zeroed by select (FULL = false instantiation).
+template <int T, bool FULL>
+__device__ __forceinline__ void load_tile_kc4(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                              float4 (&r)[2 * T], int tid) {
+    const int k = k0 + 4 * (tid & 7);
+    const int kc = FULL ? k : (k + 3 < kend ? k : kend - 4);        // KK % 4 == 0 and KK >= 4 (checked by the callers)
+#pragma unroll
+    for (int i = 0; i < 2 * T; ++i) {
+        int idx = idx0 + (tid >> 3) + 32 * i;
+        idx = idx < nidx ? idx : nidx - 1;
+        float4 v = *reinterpret_cast<const float4*>(P + (size_t)idx * ld + kc);
+        if (!FULL && k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        r[i] = v;
+    }
+}
+
+// IC operands for the split path: thread t owns idx = t % (64T) and T chunks of 8 consecutive k (dword loads,
+// coalesced along idx), so that the 8 k of a chunk leave as ONE 16-byte LDS row piece per bf16 plane.
+template <int T, bool FULL>
+__device__ __forceinline__ void load_tile_ic8(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                              float (&r)[8 * T], int tid) {
+    int idx = idx0 + tid % (64 * T);
+    idx = idx < nidx ? idx : nidx - 1;
+    const int kc = tid / (64 * T);
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 8 * (kc + (4 / T) * i) + j;
+            const int kk = FULL ? k : (k < kend ? k : kend - 1);
+            const float v = P[(size_t)kk * ld + idx];
+            r[8 * i + j] = (FULL || k < kend) ? v : 0.f;
+        }
+}
+
+// Staging is two-phase so that the conversion overlaps the MFMAs: split_tile_* turns the raw fp32 registers of the
+// NEXT stage into packed bf16 planes (VALU only, scheduled between the MFMAs of the current stage), write_tile_*
+// is the bare LDS store between the two workgroup barriers.  PK = 12T packed registers per operand.
+template <int T>
+__device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned (&pk)[12 * T]) {
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
+}
+template <int T>
+__device__ __forceinline__ void write_tile_ic8(unsigned short* __restrict__ S, const unsigned (&pk)[12 * T], int tid) {
+    constexpr int PLANE = 64 * T * SBROW;
+    const int il = tid % (64 * T), kc = tid / (64 * T);
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        unsigned short* d = S + il * SBROW + 8 * (kc + (4 / T) * i);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(d + p * PLANE) =
+                make_uint4(pk[12 * i + 4 * p], pk[12 * i + 4 * p + 1], pk[12 * i + 4 * p + 2], pk[12 * i + 4 * p + 3]);
+    }
+}
+
+template <bool PRO, int T>
+__device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigned (&pk)[12 * T], int tid, int k0,
+                                               const float* __restrict__ ps, const float* __restrict__ pt) {
+#pragma unroll
+    for (int i = 0; i < 2 * T; ++i) {
+        float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        if (PRO) {
+            const int k = 4 * (tid & 7);
+            const float4 s = *reinterpret_cast<const float4*>(ps + k0 + k);
+            const float4 t = *reinterpret_cast<const float4*>(pt + k0 + k);
+            v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
+            v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
+        }
+        split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
+        split_pair(v[2], v[3], pk[6 * i + 1], pk[6 * i + 3], pk[6 * i + 5]);
+    }
+}
+template <int T>
+__device__ __forceinline__ void write_tile_kc4(unsigned short* __restrict__ S, const unsigned (&pk)[12 * T], int tid) {
+    constexpr int PLANE = 64 * T * SBROW;
+#pragma unroll
+    for (int i = 0; i < 2 * T; ++i) {
+        unsigned short* d = S + ((tid >> 3) + 32 * i) * SBROW + 4 * (tid & 7);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * PLANE) = make_uint2(pk[6 * i + 2 * p], pk[6 * i + 2 * p + 1]);
+    }
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int LA, int LB, bool PRO, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int APL = BM * SBROW, BPL = BN * SBROW;                   // one bf16 plane of each operand (elements)
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);                  // epilogue staging (floats)
+    constexpr int TILE_F = (3 * (APL + BPL) * 2 + 3) / 4;               // operand images in floats
+    constexpr int SMEM = TILE_F > STG ? TILE_F : STG;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    unsigned short* const sA = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const sB = sA + 3 * APL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * BM, j0 = tile.x * BN;
+    const int kbeg = tile.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra4[2 * TM], rb4[2 * TN];
+    float ra8[8 * TM], rb8[8 * TN];
+    auto fetch = [&](int k0) {
+        if (k0 + BK <= kend) {                                         // wave-uniform
+            if (LA == KC) load_tile_kc4<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
+            else load_tile_ic8<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
+            if (LB == KC) load_tile_kc4<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
+            else load_tile_ic8<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
+        } else {
+            if (LA == KC) load_tile_kc4<TM, false>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
+            else load_tile_ic8<TM, false>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
+            if (LB == KC) load_tile_kc4<TN, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
+            else load_tile_ic8<TN, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
+        }
+    };
+    unsigned pka[12 * TM], pkb[12 * TN];
+    auto split = [&](int k0) {
+        if (LA == KC) split_tile_kc4<PRO, TM>(ra4, pka, tid, k0, g.pscale, g.pshift);
+        else split_tile_ic8<TM>(ra8, pka);
+        if (LB == KC) split_tile_kc4<false, TN>(rb4, pkb, tid, k0, nullptr, nullptr);
+        else split_tile_ic8<TN>(rb8, pkb);
+    };
+    auto write = [&]() {
+        if (LA == KC) write_tile_kc4<TM>(sA, pka, tid);
+        else write_tile_ic8<TM>(sA, pka, tid);
+        if (LB == KC) write_tile_kc4<TN>(sB, pkb, tid);
+        else write_tile_ic8<TN>(sB, pkb, tid);
+    };
+    auto mfma_block = [&](int kk) {
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * APL + (32 * TM * wr + 32 * a + q) * SBROW + 16 * kk + 8 * h);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bf[b][p] = *reinterpret_cast<const bf16x8*>(sB + p * BPL + (32 * TN * wc + 32 * b + q) * SBROW + 16 * kk + 8 * h);
+        // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][PA[t]], bf[b][PB[t]], acc[a][b]);
+    };
+    fetch(kbeg);
+    split(kbeg);
+    write();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // the next stage (the last step re-reads its own tile: harmless, keeps the loop body one straight block)
+        const int kn = (k0 + BK < kend) ? k0 + BK : k0;
+        fetch(kn);
+        __builtin_amdgcn_sched_barrier(0);                             // all loads in flight before the MFMAs
+        mfma_block(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(1);
+        split(kn);                                                     // VALU work for the scheduler to sink into the MFMA shadow
+        __syncthreads();                                               // every wave has read this stage
+        write();
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
 }
 
 // sum over split-K slices: out[e] = sum_z part[z][e]
@@ -375,6 +613,20 @@ template <int LA, int LB, bool PRO>
 int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     const long long big = (long long)((g.NJ + 127) / 128) * ((g.MI + 127) / 128) * nz;
     static const int use_dma = getenv("FACL_GEMM_DMA") ? atoi(getenv("FACL_GEMM_DMA")) : 1;
+    // FACL_GEMM_F32=1 selects the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split-bf16 ones
+    static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
+    if (!use_f32) {
+        if (big >= 256) {
+            dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 64;
+        } else {
+            dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 32;
+        }
+        return facl_launch_status();
+    }
     // LDS-DMA needs 16-byte aligned 4-element pieces: leading dimensions and extents multiples of 4
     // Measured A/B in one process (49152-row layers): the DMA path wins when BOTH operands are idx-contiguous
     // (wgrad: 0.431 vs 0.538 ms at 1024x512) and loses a few % when a k-contiguous operand needs the

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # same guide, BF16 dense (the split-bf16 kernels run on this pipe)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -51,52 +52,89 @@ def make_opt(a):
                            pooling="concatenation", SAMPLE_NUM=a.N)
 
 
-def dominant_kernel_roofline(a, dev):
-    """Live timing of the dominant kernel (k_sa_fwd3: y2 -> a2 -> 64->256 MFMA layer + BN stats + max/argmax)
-    with HIP events on the stream it is launched on.  Algorithmic FLOPs per launch = 2*64*256 per position x
-    M*S*K positions (the 64->256 term of the SA-MLP)."""
-    from facl_amd import _lib
-    from facl_amd.sa_mlp import _Workspace
-    lib = _lib.load_library()
-    nunits = a.B * a.T * 64
-    y2f = torch.randn(nunits * 4096, device=dev)
-    sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
-    W3, b3 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
-    sgn = torch.ones(256, device=dev)
-    ymax = torch.empty(nunits, 256, device=dev)
-    arg = torch.empty(nunits, 256, dtype=torch.uint8, device=dev)
-    sums = torch.empty(256, 2, dtype=torch.float64, device=dev)
-    ws = _Workspace.get(dev)
-    st = torch.cuda.current_stream()
-
-    def launch():
-        _lib.check(lib.facl_sa_fwd3(_lib.ptr(y2f), nunits, _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(W3), _lib.ptr(b3),
-                                    _lib.ptr(sgn), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums), _lib.ptr(ws),
-                                    st.cuda_stream), "facl_sa_fwd3")
-    for _ in range(3):
+def _time_launch(launch, st, iters=10, warm=3):
+    """Average launch duration (ms) from HIP events recorded on the stream the kernel is launched on."""
+    for _ in range(warm):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 10
     e0.record(st)
     for _ in range(iters):
         launch()
     e1.record(st)
     e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters        # includes the 2-us partial-sum reduce that follows each launch
-    flops = 2.0 * 64 * 256 * nunits * 64
-    ach = flops / (ms * 1e-3) / 1e12
+    return e0.elapsed_time(e1) / iters
+
+
+def _pmc_traffic(a, kernel):
     # HBM bytes per launch: PMC counters are collected offline (rocprofv3 --pmc, profiles/pmc_traffic.json) at this
     # exact shape; reported only when the shape matches, else null.
-    traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if pm["shape"] == {"B": a.B, "T": a.T, "N": a.N, "D": a.D}:
-            traffic = pm["k_sa_fwd3"]
+            return pm.get(kernel)
     except Exception:
-        traffic = None
-    return {"kernel": "k_sa_fwd3", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-            "ms_per_launch": round(ms, 4), "algorithmic_flops_per_launch": flops}
+        pass
+    return None
+
+
+def dominant_kernel_roofline(a, dev):
+    """Live timing (HIP events on the launch stream) of the three heaviest kernels of the step on synthetic operands of
+    the step's shapes.  `roofline` is the single longest kernel, k_sa_bwd1 (HBM-side: it streams y2 in and dz2 out,
+    its MFMA part is small); `roofline_more` carries the two MFMA kernels (k_sa_fwd3_sb and the largest k_gemm_sb),
+    priced against the bf16 MFMA peak with the bf16 FLOPs they EXECUTE (6 per fp32 multiply-add)."""
+    from facl_amd import _lib
+    from facl_amd.sa_mlp import _Workspace
+    lib, p = _lib.load_library(), _lib.ptr
+    nunits = a.B * a.T * 64
+    f32, f64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float64, device=dev)
+    y2f = torch.randn(nunits * 4096, **f32)
+    sc, sh = torch.rand(64, **f32) + 0.5, torch.randn(64, **f32) * 0.1
+    W3, b3 = torch.randn(256, 64, **f32) * 0.1, torch.randn(256, **f32) * 0.1
+    sgn = torch.ones(256, **f32)
+    ymax = torch.empty(nunits, 256, **f32)
+    arg = torch.randint(0, 64, (nunits, 256), dtype=torch.uint8, device=dev)
+    sums3, sums1 = torch.empty(256, 2, **f64), torch.empty(64, 2, **f64)
+    ws = _Workspace.get(dev)
+    st = torch.cuda.current_stream()
+    s_ = st.cuda_stream
+
+    # ---- k_sa_bwd1: y2 (16 KiB/unit) + coef (1 KiB) + arg (256 B) in, dz2 (16 KiB) out
+    bnc2 = torch.stack([torch.zeros(64, **f32), torch.ones(64, **f32), sc, sh, torch.zeros(64, **f32)]).contiguous()
+    G3, h3 = torch.randn(64, 64, **f32) * 0.01, torch.randn(64, **f32) * 0.01
+    coef = torch.randn(nunits, 256, **f32)
+    dz2f = torch.empty_like(y2f)
+    ms1 = _time_launch(lambda: _lib.check(lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg),
+                                                         p(dz2f), p(sums1), p(ws), s_), "facl_sa_bwd1"), st)
+    bytes1 = float(nunits) * (2 * 16384 + 1024 + 256)
+    ach1 = bytes1 / (ms1 * 1e-3) / 1e9
+    main = {"kernel": "k_sa_bwd1", "bound": "hbm", "achieved": round(ach1, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(ach1 / PEAK_HBM_GBPS, 4), "traffic": _pmc_traffic(a, "k_sa_bwd1"),
+            "ms_per_launch": round(ms1, 4), "algorithmic_bytes_per_launch": bytes1}
+    del dz2f, coef
+
+    # ---- k_sa_fwd3_sb: 64 -> 256 layer of the SA-MLP, 2*64*256 FLOP per position (SURVEY 8d), x6 bf16 MFMA FLOPs
+    ms3 = _time_launch(lambda: _lib.check(lib.facl_sa_fwd3(p(y2f), nunits, p(sc), p(sh), p(W3), p(b3), p(sgn), p(ymax),
+                                                         p(arg), p(sums3), p(ws), s_), "facl_sa_fwd3"), st)
+    fl3 = 2.0 * 64 * 256 * nunits * 64
+    more = [{"kernel": "k_sa_fwd3_sb", "bound": "mfma", "achieved": round(6 * fl3 / (ms3 * 1e-3) / 1e12, 1),
+             "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(6 * fl3 / (ms3 * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4),
+             "traffic": _pmc_traffic(a, "k_sa_fwd3_sb"), "ms_per_launch": round(ms3, 4), "algorithmic_flops_per_launch": fl3,
+             "algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * fl3}]
+    del y2f, ymax
+
+    # ---- largest tail GEMM (net3DV_3.6: 512 -> 1024 over the M*S centroid rows), forward
+    M, K, N = a.B * a.T * 64, 512, 1024
+    x, W, bias = torch.randn(M, K, **f32), torch.randn(N, K, **f32) * 0.05, torch.zeros(N, **f32)
+    y, gs = torch.empty(M, N, **f32), torch.empty(N, 2, **f64)
+    msg = _time_launch(lambda: _lib.check(lib.facl_gemm_fwd(p(x), M, K, p(W), K, N, p(bias), None, None, None, None, 0, p(y),
+                                                          p(gs), p(ws), s_), "facl_gemm_fwd"), st)
+    flg = 2.0 * M * K * N
+    more.append({"kernel": "k_gemm_sb<KC,KC> 49152x512x1024", "bound": "mfma", "achieved": round(6 * flg / (msg * 1e-3) / 1e12, 1),
+                 "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(6 * flg / (msg * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
+                 "ms_per_launch": round(msg, 4), "algorithmic_flops_per_launch": flg,
+                 "algorithmic_tflops": round(flg / (msg * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * flg})
+    return main, more
 
 
 def cpu_baseline(a):
@@ -180,11 +218,12 @@ def main():
         out = {"metric": "contrastive-step clips/sec (B=32,T=24,N=2048)", "value": round(clips, 2), "unit": "clips/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "dtype_note": "fp32 storage and accumulation; dense contractions as exact 3-way bf16 splits on the bf16 MFMA (6 products per multiply-add, fp32-grade accuracy)",
                "config": {"workload": f"motion stream, B={a.B}/GPU T={a.T} N={a.N} D={a.D}, S=64 K=64, full "
                                       f"cn3d_model_conbag encoder, global+circle loss, backward, Adam",
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode},
                "final_loss": final_loss}
-        out["roofline"] = dominant_kernel_roofline(a, dev)
+        out["roofline"], out["roofline_more"] = dominant_kernel_roofline(a, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
     if world > 1:

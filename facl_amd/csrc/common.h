@@ -55,3 +55,43 @@ __device__ __forceinline__ constexpr int rowmap(int r, int h) { return (r & 3) +
 
 // partial-sum workspace: every wave (or block) of a reducing kernel writes one row of doubles
 #define FACL_WS_ROWS 4096
+
+// ---- split-bf16 ("bf16x6") helpers ---------------------------------------------------------------------------
+// gfx950 runs the fp32-input MFMA at 1/16 of the bf16 rate.  An fp32 value is split EXACTLY into three bf16 pieces
+// (x = hi + mid + lo, round-to-nearest at each level) and a product is accumulated from the six piece products that
+// reach 2^-24 of |a||b|:  ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh); the three dropped ones are <= 2^-25.
+// bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32: fp32-GEMM accuracy
+// (measured slightly better than the fp32 MFMA chain: fewer roundings) at 6/16 of the fp32-MFMA time.
+// Operand lane map of the 32x32x16 MFMA: lane l (r = l&31, h = l>>5) holds A[r][8h+j] / B[8h+j][r], j = 0..7;
+// the result layout equals the 32x32x2 one (rowmap above).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+#define FACL_SB_PA {2, 0, 1, 1, 0, 0}
+#define FACL_SB_PB {0, 2, 1, 0, 1, 0}
+
+__device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
+    const f32x2v v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));       // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// two values -> packed (hi, mid, lo) bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mi, unsigned& lo) {
+    hi = pk_bf16(x0, x1);
+    // scalar subtractions on purpose: the SLP vectoriser would fuse each pair into v_pk_add_f32, which costs far more
+    // than two v_sub_f32 beside MFMAs (MI355X guide, "packed f32 VALU ... an anti-lever beside MFMAs")
+    const float r0 = sub_f32(x0, __builtin_bit_cast(float, hi << 16)), r1 = sub_f32(x1, __builtin_bit_cast(float, hi & 0xffff0000u));
+    mi = pk_bf16(r0, r1);
+    const float s0 = sub_f32(r0, __builtin_bit_cast(float, mi << 16)), s1 = sub_f32(r1, __builtin_bit_cast(float, mi & 0xffff0000u));
+    lo = pk_bf16(s0, s1);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
+    const uint4 u = make_uint4(a, b, c, d);
+    return __builtin_bit_cast(bf16x8, u);
+}

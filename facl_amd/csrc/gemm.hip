@@ -383,29 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(GemmArgs g) {
 // fp32-GEMM accuracy (tests/test_gpu_gemm.py compares both paths with an fp64 product) at 6/16 of the MFMA time.
 // LDS image per operand: [piece][idx][32 k + 8 pad] bf16 (80-B rows: the ds_read_b128 fragment reads and the
 // staging writes are conflict-free); both global layouts are transposed into it by the register staging pass.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 constexpr int SBROW = BK + 8;                  // bf16 elements per LDS row
-
-__device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
-    const f32x2v v = {x0, x1};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));       // v_cvt_pk_bf16_f32 (RNE)
-}
-__device__ __forceinline__ float sub_f32(float a, float b) {
-    float d;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mi, unsigned& lo) {
-    hi = pk_bf16(x0, x1);
-    // scalar subtractions on purpose: the SLP vectoriser would fuse each pair into v_pk_add_f32, which costs far more
-    // than two v_sub_f32 beside MFMAs (MI355X guide, "packed f32 VALU ... an anti-lever beside MFMAs")
-    const float r0 = sub_f32(x0, __builtin_bit_cast(float, hi << 16)), r1 = sub_f32(x1, __builtin_bit_cast(float, hi & 0xffff0000u));
-    mi = pk_bf16(r0, r1);
-    const float s0 = sub_f32(r0, __builtin_bit_cast(float, mi << 16)), s1 = sub_f32(r1, __builtin_bit_cast(float, mi & 0xffff0000u));
-    lo = pk_bf16(s0, s1);
-}
 
 // Branch-free tile fetches for the split path (a tile whose loads sit in 2T if/else blocks defeats the scheduler):
 // addresses are CLAMPED into the operand (rows beyond nidx re-read the last row: they only feed output rows / columns
@@ -498,7 +476,6 @@ __device__ __forceinline__ void write_tile_kc4(unsigned short* __restrict__ S, c
     }
 }
 
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 template <int LA, int LB, bool PRO, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
@@ -566,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
             for (int p = 0; p < 3; ++p)
                 bf[b][p] = *reinterpret_cast<const bf16x8*>(sB + p * BPL + (32 * TN * wc + 32 * b + q) * SBROW + 16 * kk + 8 * h);
         // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll

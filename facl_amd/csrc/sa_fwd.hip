@@ -15,6 +15,7 @@
 // A "unit" is 64 consecutive positions (= one group when K = 64).  One wave owns one unit at a time.
 // Roofline: MFMA fp32 (157.3 TFLOP/s).  FLOPs per unit: fwd2 2*64*64*64, fwd3 2*64*64*256.
 #include "common.h"
+#include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
 
@@ -308,6 +309,139 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
     }
 }
 
+// Split-bf16 (bf16x6, common.h) version of fwd3: same tiling, same epilogue, same outputs; the 64x64 a2 tile of a
+// unit never leaves the wave's registers -- the fragment-layout float4s of y2 already hold 4 consecutive channels of
+// one position, so two of them give the 8 k-slots of a 32x32x16 A operand (slot (h,j) of block kk <-> channel
+// 16kk + 4h + j for j < 4, 16kk + 8 + 4h + (j-4) else; W3's B fragments use the same map).  Per unit and wave:
+// 64 values/lane split into 3 bf16 planes (96 VGPRs), 96 ds_read_b128 of pre-split sgn*W3 fragments, 384 MFMAs.
+// Roofline: MFMA bf16 (2.5 PFLOP/s dense); 6 * 2*64*64*256 executed FLOP per unit.
+__global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2f, int nunits,
+                                                    const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                    const float* __restrict__ W3, const float* __restrict__ b3,
+                                                    const float* __restrict__ sgn3, float* __restrict__ ymax,
+                                                    unsigned char* __restrict__ arg, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    uint4* w3p = reinterpret_cast<uint4*>(lds4);         // [(ct3*4 + kk)*3 + plane][lane]: 96 KiB
+    float4* sc2s = lds4 + 6144;              // 16
+    float4* sh2s = sc2s + 16;                // 16
+    float* b3s = reinterpret_cast<float*>(sh2s + 16);   // 256
+    // per-wave fp64 (sum, sumsq) of y3 per channel: [ct3][q] (the two lane halves are merged before the update)
+    double2* stat = reinterpret_cast<double2*>(b3s + 256) + (threadIdx.x >> 6) * 256;
+    for (int i = threadIdx.x; i < 2048; i += 512) {
+        const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
+        const int c3 = 32 * ct3 + (ln & 31);
+        const float* wrow = W3 + c3 * 64 + 16 * kk + 4 * (ln >> 5);
+        float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
+        const float s = sgn3[c3];
+        unsigned hi[4], mi[4], lo[4];
+        split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
+        split_pair(w0.z * s, w0.w * s, hi[1], mi[1], lo[1]);
+        split_pair(w1.x * s, w1.y * s, hi[2], mi[2], lo[2]);
+        split_pair(w1.z * s, w1.w * s, hi[3], mi[3], lo[3]);
+        uint4* d = w3p + ((ct3 * 4 + kk) * 3) * 64 + ln;
+        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    if (threadIdx.x < 16) {
+        sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
+        sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
+    }
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn3[threadIdx.x];
+    __syncthreads();
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 8 + (threadIdx.x >> 6), nwaves = gridDim.x * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stat[i * 64 + lane] = make_double2(0.0, 0.0);
+
+    float4 yn[16];
+    auto issue_loads = [&](int u) {
+        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
+    };
+    if (wave_g < nunits) issue_loads(wave_g);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        bf16x8 ap[2][4][3];                  // [position tile][k16 block][plane]
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rt = kk >> 1, m = kk & 1;
+                unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
+                    const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
+                    split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
+                    split_pair(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1], lo[2 * t + 1]);
+                }
+                ap[ct][kk][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
+                ap[ct][kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
+                ap[ct][kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+            }
+        if (u + nwaves < nunits) issue_loads(u + nwaves);
+#pragma unroll 1
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            const float bias = b3s[32 * ct3 + q];
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = bias; }
+            constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 bfr[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, w3p[((ct3 * 4 + kk) * 3 + p) * 64 + lane]);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc0 = MFMA_BF16(ap[0][kk][PA[t]], bfr[PB[t]], acc0);
+                    acc1 = MFMA_BF16(ap[1][kk][PA[t]], bfr[PB[t]], acc1);
+                }
+            }
+            float s = 0.f, sq = 0.f, best = acc0[0];
+            int bp = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc0[r];
+                s += v; sq = fmaf(v, v, sq);
+                if (v > best) { best = v; bp = rowmap(r, 0); }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc1[r];
+                s += v; sq = fmaf(v, v, sq);
+                if (v > best) { best = v; bp = 32 + rowmap(r, 0); }
+            }
+            bp += 4 * h;
+            const float ob = __shfl_xor(best, 32, 64);
+            const int op = __shfl_xor(bp, 32, 64);
+            if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }   // first max wins (MaxPool2d)
+            if (part) {
+                const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+                if (h == 0) {
+                    double2 d = stat[ct3 * 32 + q];
+                    d.x += (double)st; d.y += (double)sqt;
+                    stat[ct3 * 32 + q] = d;
+                }
+            }
+            if (h == 0) {
+                ymax[(size_t)u * 256 + 32 * ct3 + q] = best;
+                arg[(size_t)u * 256 + 32 * ct3 + q] = (unsigned char)bp;
+            }
+        }
+    }
+    if (part && h == 0) {
+#pragma unroll
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            const double2 st = stat[ct3 * 32 + q];
+            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x;
+            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = st.y;
+        }
+    }
+}
+
 __global__ void k_sa_pool(const float* __restrict__ ymax, long long n4, int C4, const float* __restrict__ scale,
                           const float* __restrict__ shift, float* __restrict__ pooled) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -361,16 +495,24 @@ extern "C" int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 7) / 8 : SA_GRID);
-    const size_t lds = (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2);
+    // FACL_SA_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one
+    static const int use_f32 = getenv("FACL_SA_F32") ? atoi(getenv("FACL_SA_F32")) : 0;
+    const size_t lds = use_f32 ? (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2)
+                               : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 256 * sizeof(double2);
+    const void* fn = use_f32 ? (const void*)k_sa_fwd3 : (const void*)k_sa_fwd3_sb;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_sa_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     double* part = sums3 ? (double*)ws : nullptr;
-    hipLaunchKernelGGL(k_sa_fwd3, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3, ymax,
-                       arg, part);
+    if (use_f32)
+        hipLaunchKernelGGL(k_sa_fwd3, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3, ymax,
+                           arg, part);
+    else
+        hipLaunchKernelGGL(k_sa_fwd3_sb, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+                           ymax, arg, part);
     int rc = facl_launch_status();
     if (rc || !sums3) return rc;
     return facl_reduce_rows(part, grid * 8, 512, sums3, st);

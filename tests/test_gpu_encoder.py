@@ -253,7 +253,8 @@ def test_other_K_forward_backward_vs_fp64_oracle(S, K):
     from facl_amd.utils_my import knn_radius_group
     from oracle import encoder as E, grouping as OG
     from oracle.weights import formula_state_dict
-    D, B, G, N = 4, 2, 3, 512
+    # B*G = 24 clouds: netR_FC's BatchNorm1d over only 6 rows (B = 2) amplified fp32 rounding to ~1e-2 by itself
+    D, B, G, N = 4, 8, 3, 512
     torch.manual_seed(K)
     pts = torch.rand(G * B, N, D) - 0.5
     opt = _opt(D, B, N)
@@ -283,10 +284,10 @@ def test_other_K_forward_backward_vs_fp64_oracle(S, K):
     for k, p in net.named_parameters():
         if k not in sa_keys:
             continue
-        # end-to-end gradients carry the max-pool tie-flip noise floor (see test_c1_golden...) amplified by the
-        # BatchNorm1d over only B*G = 6 rows; the noise is absolute, so small-norm parameters (net3DV_1.7.bias, 1e-3
-        # of the largest) are scaled like tests/test_oracle_golden.py does.  The tight kernel-level check for these K
-        # is tests/test_gpu_sa_mlp.py::test_sa_other_K_kernel_level
+        # End-to-end gradients are bimodal: ~5e-6 when every max-pool argmax agrees with the fp64 oracle, ~5e-3..1e-2
+        # as soon as ONE near-tie (two neighbours within fp32 rounding) resolves the other way -- which happens for the
+        # fp32-MFMA and the split-bf16 kernels alike, on different seeds.  The bound covers the flip floor; the tight
+        # kernel-level check for these K is tests/test_gpu_sa_mlp.py::test_sa_other_K_kernel_level
         ref = sd[k].grad.numpy()
         err = float(np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - ref))
         assert err <= 3e-2 * max(float(np.linalg.norm(ref)), 1e-2 * gmax), (k, err)

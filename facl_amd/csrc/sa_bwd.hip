@@ -61,7 +61,18 @@ __global__ __launch_bounds__(256) void k_sa_bwd0(const float* __restrict__ dpool
 
 // ---------------------------------------------------------------------------------------------
 // bwd1.  LDS: g3f 16 KiB | w3n 64 KiB | tables | 4 x T (64 x 68 floats).
-__global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, int nunits,
+// Producer/consumer workgroup of 8 waves = 4 pairs, one unit per pair and round.  The two halves of the work use
+// different hardware and used to run back to back in one wave (40k cycles per unit at 1 wave/SIMD):
+//   * "scatter" wave (waves 4-7): the sparse rows  T[arg[c]][j] += coef[c] * W3[c][j]  -- VALU/SALU/LDS-read bound,
+//     64 row accumulators in registers through GPR indexing (sa_bwd1_scatter.inc);
+//   * "dense" wave (waves 0-3): a2 -> a2 G3 + h3' on the MFMA, then combine with T, mask, store dz2, dbeta2/dgamma2.
+// Wave w and w+4 land on the same SIMD (4 SIMDs, cyclic placement), so every SIMD runs one wave of each kind and the
+// MFMA pipe works in the shadow of the scatter's instruction stream.  Hand-off through the pair's single T tile with two
+// workgroup barriers per round:  A = "dense has finished reading the previous T" (inside the scatter's asm block, just
+// before its 64 row stores),  B = "T is written".  Between B and the next A the dense wave does ALL of its unit (MFMAs
+// and epilogue, one output-channel half at a time to stay inside 256 registers) while the scatter wave accumulates the
+// next unit in registers: the two roles are skewed by one unit.
+__global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, int nunits,
                                                  const float* __restrict__ bnc2, const float* __restrict__ G3,
                                                  const float* __restrict__ h3, const float* __restrict__ W3,
                                                  const float* __restrict__ coef, const unsigned char* __restrict__ arg,
@@ -70,12 +81,14 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
     float4* g3f = lds4;                                   // [rt'][rt][r4][lane]  (1024 float4)
     float* w3n = reinterpret_cast<float*>(lds4 + 1024);   // W3 natural (256,64)
     float4* tab = lds4 + 1024 + 4096;                     // mean2, invstd2, scale2, shift2, h3: 5 x 16 float4
-    float* T = reinterpret_cast<float*>(tab + 80) + (threadIdx.x >> 6) * (64 * TP);
-    for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave & 3;
+    float* T = reinterpret_cast<float*>(tab + 80) + pair * (64 * TP);
+    for (int i = threadIdx.x; i < 1024; i += 512) {
         const int ln = i & 63, r4 = (i >> 6) & 3, rt = (i >> 8) & 1, rto = i >> 9;
         g3f[i] = *reinterpret_cast<const float4*>(G3 + (32 * rto + (ln & 31)) * 64 + 32 * rt + 8 * r4 + 4 * (ln >> 5));
     }
-    for (int i = threadIdx.x; i < 4096; i += 256)
+    for (int i = threadIdx.x; i < 4096; i += 512)
         reinterpret_cast<float4*>(w3n)[i] = reinterpret_cast<const float4*>(W3)[i];
     if (threadIdx.x < 64) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2)[threadIdx.x];   // 4 x 64 floats
     if (threadIdx.x < 16) tab[64 + threadIdx.x] = reinterpret_cast<const float4*>(h3)[threadIdx.x];
@@ -84,53 +97,81 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
     const float4* h3s = tab + 64;
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int nw = gridDim.x * 4;                         // units in flight over the whole grid
+    const int u0 = blockIdx.x * 4 + pair;
+    // every wave of the workgroup runs the same number of rounds (the barriers are workgroup-wide): pair 0's count
+    const int rounds = (nunits - (int)blockIdx.x * 4 + nw - 1) / nw;
+
+    if (wave >= 4) {
+        // =================================================================== scatter role
+        float4 cfn = make_float4(0.f, 0.f, 0.f, 0.f);
+        uchar4 arn = make_uchar4(0, 0, 0, 0);
+        if (u0 < nunits) {
+            cfn = *reinterpret_cast<const float4*>(coef + (size_t)u0 * 256 + 4 * lane);
+            arn = *reinterpret_cast<const uchar4*>(arg + (size_t)u0 * 256 + 4 * lane);
+        }
+        for (int r = 0; r < rounds; ++r) {
+            const int u = u0 + r * nw;
+            // an inactive pair (u >= nunits in the last round) runs the block on zero coefficients: T is never read then
+            const float4 cf4 = cfn;
+            const uchar4 ar4 = arn;
+            if (u + nw < nunits) {
+                cfn = *reinterpret_cast<const float4*>(coef + (size_t)(u + nw) * 256 + 4 * lane);
+                arn = *reinterpret_cast<const uchar4*>(arg + (size_t)(u + nw) * 256 + 4 * lane);
+            } else {
+                cfn = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float cfv[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
+            const int arv[4] = {ar4.x & 63, ar4.y & 63, ar4.z & 63, ar4.w & 63};   // GPR index: must stay inside v192..v255
+            {
+                // 64 row accumulators in v192..v255, addressed by GPR indexing (SRC2+DST) inside ONE hand-written block:
+                // per element 2 v_readlane + s_set_gpr_idx_idx + v_fma (hipcc's own indexed RMW costs ~110 cycles per
+                // element because it toggles the index mode around separate read / add / write moves).  The block
+                // ends with  s_barrier (A)  +  the 64 row stores into T.
+                float w0, w1, w2, w3, x0, x1, x2, x3;
+                unsigned wa, si, szero, sm0, sc0, sc1, sc2_, sc3, sp0, sp1, sp2, sp3;
+                const unsigned waddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(w3n + lane));   // LDS byte address
+                const unsigned taddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(T + lane));
+                asm volatile(FACL_SCATTER_ASM_TEXT
+                             : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [x0] "=&v"(x0), [x1] "=&v"(x1),
+                               [x2] "=&v"(x2), [x3] "=&v"(x3), [wa] "=&v"(wa), [i] "=&s"(si),
+                               [zero] "=&s"(szero), [m0s] "=&s"(sm0), [c0] "=&s"(sc0), [c1] "=&s"(sc1), [c2] "=&s"(sc2_),
+                               [c3] "=&s"(sc3), [p0] "=&s"(sp0), [p1] "=&s"(sp1), [p2] "=&s"(sp2), [p3] "=&s"(sp3)
+                             : [cf0] "v"(cfv[0]), [cf1] "v"(cfv[1]), [cf2] "v"(cfv[2]), [cf3] "v"(cfv[3]), [ar0] "v"(arv[0]),
+                               [ar1] "v"(arv[1]), [ar2] "v"(arv[2]), [ar3] "v"(arv[3]), [waddr] "v"(waddr), [ta] "v"(taddr)
+                             : FACL_SCATTER_ASM_CLOBBERS);
+            }
+            WAVE_LDS_FENCE();                 // the row stores have landed
+            __builtin_amdgcn_s_barrier();     // B
+        }
+        return;
+    }
+
+    // ======================================================================= dense role
     float pb[2][16], pg[2][16];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { pb[a][r] = 0.f; pg[a][r] = 0.f; }
 
-    // register double buffer (see k_sa_bwd_w3): next unit's y2 tile, coef and arg are in flight during this unit
-    float4 yn[16], cfn;
-    uchar4 arn;
-    auto issue_loads = [&](int u) {
-        const float* tl = y2f + (size_t)u * FACL_UNIT_ELEMS;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tl + (i * 64 + lane) * 4);
-        cfn = *reinterpret_cast<const float4*>(coef + (size_t)u * 256 + 4 * lane);
-        arn = *reinterpret_cast<const uchar4*>(arg + (size_t)u * 256 + 4 * lane);
-    };
-    if (wave_g < nunits) issue_loads(wave_g);
-    for (int u = wave_g; u < nunits; u += nwaves) {
+    // No register double buffer here (256 registers: y 64 + dbeta/dgamma partials 64 + accumulators 32 + operands): the
+    // unit's y2 tile is requested BEFORE the two barriers and consumed after them, so the time this wave waits for
+    // its scatter partner covers the load latency.
+    for (int r = 0; r < rounds; ++r) {
+        const int u = u0 + r * nw;
+        const bool active = u < nunits;       // wave-uniform
         asm volatile("" ::: "memory");
-        // ---- sparse rows: srow[arg[c]][j] += coef[c] * W3[c][j]   (lane = channel j)
-        // The target row is WAVE-UNIFORM, so the 64 row accumulators live in registers and are addressed
-        // with GPR indexing (s_set_gpr_idx): no LDS atomics (ds_add_f32 measured ~700 cycles per
-        // wave-instruction on gfx950: 3.6 of this kernel's 4.2 ms), no memory traffic at all.
-        const float4 cf4 = cfn;
-        const uchar4 ar4 = arn;
-        const float cfv[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
-        const int arv[4] = {ar4.x, ar4.y, ar4.z, ar4.w};
-        {
-            // 64 row accumulators in v192..v255, addressed by GPR indexing (SRC2+DST) inside ONE hand-written block:
-            // per element 2 v_readlane + s_set_gpr_idx_idx + v_fma (hipcc's own indexed RMW costs ~110 cycles per
-            // element because it toggles the index mode around separate read / add / write moves).
-            float w0, w1, w2, w3, x0, x1, x2, x3;
-            unsigned wa, si, szero, sm0, sc0, sc1, sc2, sc3, sp0, sp1, sp2, sp3;
-            const unsigned waddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(w3n + lane));   // LDS byte address
-            const unsigned taddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(T + lane));
-            asm volatile(FACL_SCATTER_ASM_TEXT
-                         : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [x0] "=&v"(x0), [x1] "=&v"(x1),
-                           [x2] "=&v"(x2), [x3] "=&v"(x3), [wa] "=&v"(wa), [i] "=&s"(si),
-                           [zero] "=&s"(szero), [m0s] "=&s"(sm0), [c0] "=&s"(sc0), [c1] "=&s"(sc1), [c2] "=&s"(sc2),
-                           [c3] "=&s"(sc3), [p0] "=&s"(sp0), [p1] "=&s"(sp1), [p2] "=&s"(sp2), [p3] "=&s"(sp3)
-                         : [cf0] "v"(cfv[0]), [cf1] "v"(cfv[1]), [cf2] "v"(cfv[2]), [cf3] "v"(cfv[3]), [ar0] "v"(arv[0]),
-                           [ar1] "v"(arv[1]), [ar2] "v"(arv[2]), [ar3] "v"(arv[3]), [waddr] "v"(waddr), [ta] "v"(taddr)
-                         : FACL_SCATTER_ASM_CLOBBERS);
+        float4 yn[16];
+        if (active) {
+            const float* tl = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tl + (i * 64 + lane) * 4);
         }
-        WAVE_LDS_FENCE();      // other lanes read T below
-        // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // A: this wave's reads of the previous T are complete
+        __builtin_amdgcn_s_barrier();         // B: the scatter wave has written this unit's T
+        asm volatile("" ::: "memory");
+        if (!active) continue;
         float yv[2][2][16];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -141,72 +182,90 @@ __global__ __launch_bounds__(256) void k_sa_bwd1(const float* __restrict__ y2f, 
                     const float4 y = yn[(ct * 2 + rt) * 4 + r4];
                     yv[ct][rt][4 * r4] = y.x; yv[ct][rt][4 * r4 + 1] = y.y; yv[ct][rt][4 * r4 + 2] = y.z; yv[ct][rt][4 * r4 + 3] = y.w;
                 }
-        if (u + nwaves < nunits) issue_loads(u + nwaves);
-        f32x16 acc[2][2];
+        // One output-channel half (ro) at a time: 64 MFMAs into 32 accumulators, then that half's epilogue.  The whole
+        // unit runs while the scatter wave accumulates the NEXT unit.  Table / fragment / T reads are software-pipelined
+        // one step ahead by hand and fenced with sched_barrier: left alone, the scheduler hoists all of a section's LDS
+        // reads to its top (100+ extra live registers -> scratch spills at the 256-register budget).
+        float* otile = dz2f + (size_t)u * FACL_UNIT_ELEMS;
 #pragma unroll
-        for (int ro = 0; ro < 2; ++ro)
+        for (int ro = 0; ro < 2; ++ro) {
+            // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j]
+            f32x16 acc[2];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4 hh = h3s[8 * ro + 2 * r4 + h];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    acc[ro][ct][4 * r4] = hh.x; acc[ro][ct][4 * r4 + 1] = hh.y; acc[ro][ct][4 * r4 + 2] = hh.z; acc[ro][ct][4 * r4 + 3] = hh.w;
+                    acc[ct][4 * r4] = hh.x; acc[ct][4 * r4 + 1] = hh.y; acc[ct][4 * r4 + 2] = hh.z; acc[ct][4 * r4 + 3] = hh.w;
                 }
             }
+            float4 scn = sc2[h], shn = sh2[h], fn = g3f[(ro * 2 * 4) * 64 + lane];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 sc = sc2[8 * rt + 2 * r4 + h], sh = sh2[8 * rt + 2 * r4 + h];
-                const float4 f0 = g3f[((0 * 2 + rt) * 4 + r4) * 64 + lane], f1 = g3f[((1 * 2 + rt) * 4 + r4) * 64 + lane];
+            for (int st = 0; st < 8; ++st) {
+                const int rt = st >> 2, r4 = st & 3;
+                const float4 sc = scn, sh = shn, f0 = fn;
+                if (st < 7) {
+                    const int rtn = (st + 1) >> 2, r4n = (st + 1) & 3;
+                    scn = sc2[8 * rtn + 2 * r4n + h]; shn = sh2[8 * rtn + 2 * r4n + h];
+                    fn = g3f[((ro * 2 + rtn) * 4 + r4n) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                const float fa0[4] = {f0.x, f0.y, f0.z, f0.w}, fa1[4] = {f1.x, f1.y, f1.z, f1.w};
+                const float fa0[4] = {f0.x, f0.y, f0.z, f0.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a20 = fmaxf(fmaf(scv[e], yv[0][rt][4 * r4 + e], shv[e]), 0.f);
                     const float a21 = fmaxf(fmaf(scv[e], yv[1][rt][4 * r4 + e], shv[e]), 0.f);
-                    acc[0][0] = MFMA32(fa0[e], a20, acc[0][0]);
-                    acc[0][1] = MFMA32(fa0[e], a21, acc[0][1]);
-                    acc[1][0] = MFMA32(fa1[e], a20, acc[1][0]);
-                    acc[1][1] = MFMA32(fa1[e], a21, acc[1][1]);
+                    acc[0] = MFMA32(fa0[e], a20, acc[0]);
+                    acc[1] = MFMA32(fa0[e], a21, acc[1]);
                 }
             }
-        // ---- combine, mask with z2 > 0, store dz2, accumulate dbeta2 / dgamma2
-        float* otile = dz2f + (size_t)u * FACL_UNIT_ELEMS;
+            // ---- combine, mask with z2 > 0, store dz2, accumulate dbeta2 / dgamma2
+            float4 tn0 = *reinterpret_cast<const float4*>(&T[q * TP + 32 * ro + 4 * h]);
+            float4 tn1 = *reinterpret_cast<const float4*>(&T[(32 + q) * TP + 32 * ro + 4 * h]);
+            float4 escn = sc2[8 * ro + h], eshn = sh2[8 * ro + h], emun = mean2[8 * ro + h], eivn = inv2[8 * ro + h];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 t0 = tn0, t1 = tn1, sc = escn, sh = eshn, mu = emun, iv = eivn;
+                if (r4 < 3) {
+                    tn0 = *reinterpret_cast<const float4*>(&T[q * TP + 32 * ro + 8 * (r4 + 1) + 4 * h]);
+                    tn1 = *reinterpret_cast<const float4*>(&T[(32 + q) * TP + 32 * ro + 8 * (r4 + 1) + 4 * h]);
+                    escn = sc2[8 * ro + 2 * (r4 + 1) + h]; eshn = sh2[8 * ro + 2 * (r4 + 1) + h];
+                    emun = mean2[8 * ro + 2 * (r4 + 1) + h]; eivn = inv2[8 * ro + 2 * (r4 + 1) + h];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, ivv[4] = {iv.x, iv.y, iv.z, iv.w};
 #pragma unroll
-            for (int ro = 0; ro < 2; ++ro)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 t = *reinterpret_cast<const float4*>(&T[(32 * ct + q) * TP + 32 * ro + 8 * r4 + 4 * h]);
-                    const float4 sc = sc2[8 * ro + 2 * r4 + h], sh = sh2[8 * ro + 2 * r4 + h];
-                    const float4 mu = mean2[8 * ro + 2 * r4 + h], iv = inv2[8 * ro + 2 * r4 + h];
-                    const float tv[4] = {t.x, t.y, t.z, t.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, ivv[4] = {iv.x, iv.y, iv.z, iv.w};
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float4 t = ct ? t1 : t0;
+                    const float tv[4] = {t.x, t.y, t.z, t.w};
                     float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float y = yv[ct][ro][4 * r4 + e];
                         const bool on = fmaf(scv[e], y, shv[e]) > 0.f;
-                        const float d = on ? acc[ro][ct][4 * r4 + e] + tv[e] : 0.f;
+                        const float d = on ? acc[ct][4 * r4 + e] + tv[e] : 0.f;
                         o[e] = d;
                         pb[ro][4 * r4 + e] += d;
                         pg[ro][4 * r4 + e] = fmaf(d, (y - muv[e]) * ivv[e], pg[ro][4 * r4 + e]);
                     }
                     *reinterpret_cast<float4*>(otile + (((ct * 2 + ro) * 4 + r4) * 64 + lane) * 4) = make_float4(o[0], o[1], o[2], o[3]);
                 }
+            }
+        }
     }
+    const int wave_g = blockIdx.x * 4 + pair;
 #pragma unroll
     for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            double s = pb[ro][r], g = pg[ro][r];
+            double sdb = pb[ro][r], g = pg[ro][r];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); g += __shfl_xor(g, o, 64); }
+            for (int o = 16; o > 0; o >>= 1) { sdb += __shfl_xor(sdb, o, 64); g += __shfl_xor(g, o, 64); }
             if (q == 0) {
                 const int c = 32 * ro + rowmap(r, h);
-                part[(size_t)wave_g * 128 + 2 * c] = s;
+                part[(size_t)wave_g * 128 + 2 * c] = sdb;
                 part[(size_t)wave_g * 128 + 2 * c + 1] = g;
             }
         }
@@ -534,7 +593,7 @@ extern "C" int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2,
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_sa_bwd1, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, G3, h3, W3, coef, arg, dz2f,
+    hipLaunchKernelGGL(k_sa_bwd1, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, bnc2, G3, h3, W3, coef, arg, dz2f,
                        (double*)ws);
     int rc = facl_launch_status();
     if (rc) return rc;

@@ -281,7 +281,7 @@ constexpr int W3_V = 256 * 64 + 64 * 64 + 64;
 
 __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f, int nunits,
                                                    const float* __restrict__ bnc2, const float* __restrict__ coef,
-                                                   const unsigned char* __restrict__ arg, double* __restrict__ part, int dbg) {
+                                                   const unsigned char* __restrict__ arg, double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* tab = lds4;                                         // scale2, shift2: 2 x 16 float4
     float* comb = reinterpret_cast<float*>(lds4 + 32);          // [256][65] sparse dW3 combine (padded rows)
@@ -342,7 +342,6 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
         if (u + nwaves < nunits) issue_loads(u + nwaves);
         WAVE_LDS_FENCE();
         // Gram: G[i][j] += sum_p a2[p][i] a2[p][j]; operands (lane = channel, k = position 32h+s)
-        if (!(dbg & 1))
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const float a0 = T[(32 * h + s) * TP + q], a1 = T[(32 * h + s) * TP + 32 + q];
@@ -351,8 +350,7 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
             g11 = MFMA32(a1, a1, g11);
             s2a += a0; s2b += a1;
         }
-        // sparse part of dW3
-        if (!(dbg & 2))
+        // sparse part of dW3 (same basic block as the Gram MFMAs: the scheduler sinks these FMAs into the MFMA shadow)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float4* row = reinterpret_cast<const float4*>(&T[psv[e] * TP]);
@@ -613,8 +611,7 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    static int dbg = getenv("FACL_DBG") ? atoi(getenv("FACL_DBG")) : 0;
-    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, dbg);
+    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws);
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, grid, W3_V, out, st);

@@ -6,20 +6,24 @@
 
 namespace {
 
-// part[rows][V] -> out[V]  (deterministic: fixed order, no atomics).  Block = 64 columns x 16 row groups.
+// part[rows][V] -> out[V]  (deterministic: fixed order, no atomics).  Block = 64 columns x 16 row groups; blockIdx.y
+// selects a contiguous slice of `rows_per_block` rows and writes row blockIdx.y of `out` (two-level reduction: the
+// partial-sum matrices are up to 12 MB and V/64 blocks alone left the kernel latency-bound at ~10 us a call).
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ part, int rows, int V,
-                                                      double* __restrict__ out) {
+                                                      int rows_per_block, double* __restrict__ out) {
     __shared__ double red[16][64];
     const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int v = blockIdx.x * 64 + col;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     double s0 = 0, s1 = 0;
     if (v < V) {
-        int r = rg;
-        for (; r + 16 < rows; r += 32) {
+        int r = r0 + rg;
+        for (; r + 16 < r1; r += 32) {
             s0 += part[(size_t)r * V + v];
             s1 += part[(size_t)(r + 16) * V + v];
         }
-        if (r < rows) s0 += part[(size_t)r * V + v];
+        if (r < r1) s0 += part[(size_t)r * V + v];
     }
     red[rg][col] = s0 + s1;
     __syncthreads();
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
         double t = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][col];
-        out[v] = t;
+        out[(size_t)blockIdx.y * V + v] = t;
     }
 }
 
@@ -103,8 +107,26 @@ __global__ void k_l1tab(const float* __restrict__ W1, const float* __restrict__ 
 
 }  // namespace
 
+// The partials occupy part[0 : rows*V] of the caller's workspace (facl_ws_bytes); the second level's scratch rows
+// go right behind them when they fit, else the reduction stays single-level.
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_rows, dim3((V + 63) / 64), dim3(1024), 0, st, part, rows, V, out);
+    const int cb = (V + 63) / 64;
+    int nb = 1;
+    if (rows >= 128 && cb < 128) {
+        nb = 256 / cb;                                   // ~256 workgroups in the first level
+        if (nb > rows / 32) nb = rows / 32;              // at least 32 rows (2 per row group) per block
+        if (nb < 1) nb = 1;
+    }
+    const size_t cap = (size_t)facl_ws_bytes() / sizeof(double);
+    if (nb > 1 && (size_t)rows * V + (size_t)nb * V <= cap) {
+        const int rpb = (rows + nb - 1) / nb;
+        nb = (rows + rpb - 1) / rpb;
+        double* scratch = const_cast<double*>(part) + (size_t)rows * V;
+        hipLaunchKernelGGL(k_reduce_rows, dim3(cb, nb), dim3(1024), 0, st, part, rows, V, rpb, scratch);
+        hipLaunchKernelGGL(k_reduce_rows, dim3(cb, 1), dim3(1024), 0, st, scratch, nb, V, nb, out);
+    } else {
+        hipLaunchKernelGGL(k_reduce_rows, dim3(cb, 1), dim3(1024), 0, st, part, rows, V, rows, out);
+    }
     return facl_launch_status();
 }
 

@@ -43,7 +43,7 @@ def gemm_wgrad(dy, a):
     M, N = dy.shape
     K = a.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    nz = max(1, min((M + 255) // 256, 768 // tiles))
+    nz = max(1, min((M + 255) // 256, 512 // tiles))     # tiles * nz = one resident wave of workgroups (2 per CU)
     dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = torch.empty(nz * N * K, dtype=torch.float32, device=dy.device)
     _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,

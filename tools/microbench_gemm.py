@@ -15,6 +15,7 @@ dev = torch.device("cuda:0")
 ws = _Workspace.get(dev)
 p = _lib.ptr
 M = 49152
+NZT = int(os.environ.get("NZT", "512"))
 for K, N in [(256, 256), (256, 512), (512, 1024)]:
     a = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) / K ** 0.5
@@ -24,7 +25,7 @@ for K, N in [(256, 256), (256, 512), (512, 1024)]:
     da = torch.empty(M, K, device=dev)
     dW = torch.empty(N, K, device=dev)
     sums = torch.empty(N, 2, dtype=torch.float64, device=dev)
-    nz = max(1, min(M // 256, 768 // ((N // 128) * (K // 128))))
+    nz = max(1, min(M // 256, NZT // ((N // 128) * (K // 128))))
     slices = torch.empty(nz * N * K, device=dev)
     st = _lib.stream()
     fl = 2.0 * M * N * K

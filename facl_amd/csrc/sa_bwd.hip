@@ -104,41 +104,32 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
 
     if (wave >= 4) {
         // =================================================================== scatter role
+        // The asm block reads the unit's 256 coefficients / argmax bytes through scalar loads; the vector loads below
+        // only warm the NEXT unit's rows into L2 one round ahead (their values are handed to the block as unused
+        // operands so that they are not optimised away).
         float4 cfn = make_float4(0.f, 0.f, 0.f, 0.f);
-        uchar4 arn = make_uchar4(0, 0, 0, 0);
-        if (u0 < nunits) {
-            cfn = *reinterpret_cast<const float4*>(coef + (size_t)u0 * 256 + 4 * lane);
-            arn = *reinterpret_cast<const uchar4*>(arg + (size_t)u0 * 256 + 4 * lane);
-        }
+        unsigned arn = 0;
+        const int ulast = nunits - 1;
         for (int r = 0; r < rounds; ++r) {
             const int u = u0 + r * nw;
-            // an inactive pair (u >= nunits in the last round) runs the block on zero coefficients: T is never read then
+            // an inactive pair (u >= nunits in the last round) re-runs the last unit: its T is never read
+            const int uc = u < nunits ? u : ulast, un = u + nw < nunits ? u + nw : ulast;
+            const float* cu = coef + (size_t)uc * 256;
+            const unsigned char* au = arg + (size_t)uc * 256;
             const float4 cf4 = cfn;
-            const uchar4 ar4 = arn;
-            if (u + nw < nunits) {
-                cfn = *reinterpret_cast<const float4*>(coef + (size_t)(u + nw) * 256 + 4 * lane);
-                arn = *reinterpret_cast<const uchar4*>(arg + (size_t)(u + nw) * 256 + 4 * lane);
-            } else {
-                cfn = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const float cfv[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
-            const int arv[4] = {ar4.x & 63, ar4.y & 63, ar4.z & 63, ar4.w & 63};   // GPR index: must stay inside v192..v255
+            const unsigned ar4 = arn;
+            cfn = *reinterpret_cast<const float4*>(coef + (size_t)un * 256 + 4 * lane);
+            arn = *reinterpret_cast<const unsigned*>(arg + (size_t)un * 256 + 4 * lane);
             {
-                // 64 row accumulators in v192..v255, addressed by GPR indexing (SRC2+DST) inside ONE hand-written block:
-                // per element 2 v_readlane + s_set_gpr_idx_idx + v_fma (hipcc's own indexed RMW costs ~110 cycles per
-                // element because it toggles the index mode around separate read / add / write moves).  The block
-                // ends with  s_barrier (A)  +  the 64 row stores into T.
-                float w0, w1, w2, w3, x0, x1, x2, x3;
-                unsigned wa, si, szero, sm0, sc0, sc1, sc2_, sc3, sp0, sp1, sp2, sp3;
+                // 64 row accumulators in v192..v255, addressed by GPR indexing (SRC2+DST) inside ONE hand-written block
+                // (tools/gen_scatter_asm.py): per element s_bfe + s_set_gpr_idx_idx + s_nop + v_fma + one ds_read_b32
+                // (hipcc's own indexed RMW costs ~110 cycles per element because it toggles the index mode around
+                // separate read / add / write moves).  The block ends with  s_barrier (A)  +  the 64 row stores into T.
                 const unsigned waddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(w3n + lane));   // LDS byte address
                 const unsigned taddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)(T + lane));
                 asm volatile(FACL_SCATTER_ASM_TEXT
-                             : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [x0] "=&v"(x0), [x1] "=&v"(x1),
-                               [x2] "=&v"(x2), [x3] "=&v"(x3), [wa] "=&v"(wa), [i] "=&s"(si),
-                               [zero] "=&s"(szero), [m0s] "=&s"(sm0), [c0] "=&s"(sc0), [c1] "=&s"(sc1), [c2] "=&s"(sc2_),
-                               [c3] "=&s"(sc3), [p0] "=&s"(sp0), [p1] "=&s"(sp1), [p2] "=&s"(sp2), [p3] "=&s"(sp3)
-                             : [cf0] "v"(cfv[0]), [cf1] "v"(cfv[1]), [cf2] "v"(cfv[2]), [cf3] "v"(cfv[3]), [ar0] "v"(arv[0]),
-                               [ar1] "v"(arv[1]), [ar2] "v"(arv[2]), [ar3] "v"(arv[3]), [waddr] "v"(waddr), [ta] "v"(taddr)
+                             :
+                             : [cp] "s"(cu), [ap] "s"(au), [wa] "v"(waddr), [ta] "v"(taddr), "v"(cf4.x), "v"(ar4)
                              : FACL_SCATTER_ASM_CLOBBERS);
             }
             WAVE_LDS_FENCE();                 // the row stores have landed

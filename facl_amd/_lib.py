@@ -47,6 +47,8 @@ SIGNATURES = {
     "facl_gemm_dgrad": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_wgrad": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "facl_contrast": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_build_views_f32": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
+    "facl_build_views_f64": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "facl_sa_bwd0": [c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_bwd1": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_bwd_w3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p],

@@ -193,6 +193,19 @@ int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, in
 int facl_contrast(const float* sim, int R, int J, int B, int Bk, int nA, int nS, int slot_rows,
                   const int32_t* poscol, int clip_offset, float* dsim, double* loss, void* ws, void* stream);
 
+/* ---- view construction of a batch of clips (replaces the NumPy pipeline of
+ * training_code/cn3D_data_set.py:285-350 get_data_train + :654-663 + :708-713 + :734-749 + :767-778 and the
+ * float64->float32 / permute head of cn3d_train_motion_GL.py:225-228) ----------------------------
+ * src (rows,C>=8): the batch's source clouds packed row-wise (xyz, channels 3..7); idx (B,10,512): row of src for
+ * every output point (views: raw, reversed, key, key-reversed, rotated x2, temporal ch4, temporal ch7, low-res x2);
+ * noise (B,7,512,3): the standard-normal jitter draws in the reference's order; cossin (B,2,2): cos, sin of the two
+ * rotation angles.  The host draws all of them (NumPy order) -- facl_amd/views.py.
+ * out (10*B,512,4) float32, view-major (row g*B+b).  _f32/_f64 = dtype of the source arrays. */
+int facl_build_views_f32(const float* src, int64_t rows, int C, const int32_t* idx, const double* noise,
+                         const double* cossin, int B, float* out, void* stream);
+int facl_build_views_f64(const double* src, int64_t rows, int C, const int32_t* idx, const double* noise,
+                         const double* cossin, int B, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,6 +275,29 @@ extern "C" int facl_sa_bwd_consts3(const double* sums0, const float* bnc3, const
     return facl_launch_status();
 }
 
+// BN backward of a row layer: (dbeta, dgamma) sums -> the two fp32 parameter gradients (THIS rank's sums) and the (2,C)
+// constants kk = (dbeta/P, dgamma/P) of the SyncBN-reduced sums that facl_rows_bwd_apply / facl_segmax_bwd_apply take.
+__global__ void k_bn_bwd_consts(const double* __restrict__ sums_l, const double* __restrict__ sums_g, int C, double P,
+                                float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ kk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums_l[2 * c];
+    dgamma[c] = (float)sums_l[2 * c + 1];
+    // same arithmetic as the torch glue it replaces: fp32 sum times fp32 reciprocal count
+    const float inv = (float)(1.0 / P);
+    kk[c] = (float)sums_g[2 * c] * inv;
+    kk[C + c] = (float)sums_g[2 * c + 1] * inv;
+}
+
+extern "C" int facl_bn_bwd_consts(const double* sums_local, const double* sums_global, int C, double P, float* dbeta,
+                                  float* dgamma, float* kk, void* stream) {
+    if (!sums_local || !sums_global || !dbeta || !dgamma || !kk) return FACL_E_NULL;
+    if (C < 1 || P < 1) return FACL_E_SHAPE;
+    hipLaunchKernelGGL(k_bn_bwd_consts, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums_local, sums_global,
+                       C, P, dbeta, dgamma, kk);
+    return facl_launch_status();
+}
+
 extern "C" int facl_sa_bwd_consts2(const double* sums1, const float* bnc2, double P, float* bw2, void* stream) {
     if (!sums1 || !bnc2 || !bw2) return FACL_E_NULL;
     if (P < 1) return FACL_E_SHAPE;

@@ -571,13 +571,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
     gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
 }
 
-// sum over split-K slices: out[e] = sum_z part[z][e]
+// sum over split-K slices: out[e] = sum_z part[z][e], slices added in order (deterministic); four slice loads in flight
+// per thread (a serial chain of nz dependent 16-byte loads per thread ran at a third of the HBM rate)
 __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n4, float* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 s = reinterpret_cast<const float4*>(part)[i];
-        for (int z = 1; z < nz; ++z) {
-            const float4 v = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + i];
+        float4 s = p4[i];
+        int z = 1;
+        for (; z + 3 < nz; z += 4) {
+            const float4 v0 = p4[(size_t)z * n4 + i], v1 = p4[(size_t)(z + 1) * n4 + i];
+            const float4 v2 = p4[(size_t)(z + 2) * n4 + i], v3 = p4[(size_t)(z + 3) * n4 + i];
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; z < nz; ++z) {
+            const float4 v = p4[(size_t)z * n4 + i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         reinterpret_cast<float4*>(out)[i] = s;

@@ -59,6 +59,17 @@ def _stats(y, ws):
     return sums
 
 
+def _bn_bwd_consts(sums, C, count, reduce_fn):
+    """(dbeta, dgamma) fp64 sums -> fp32 parameter gradients of THIS rank + kk (2,C) = SyncBN-reduced sums / P."""
+    lib = _lib.load_library()
+    f32 = dict(dtype=torch.float32, device=sums.device)
+    dbeta, dgamma, kk = torch.empty(C, **f32), torch.empty(C, **f32), torch.empty((2, C), **f32)
+    sums_g = reduce_fn(sums.clone()) if reduce_fn is not None else sums
+    _lib.check(lib.facl_bn_bwd_consts(_lib.ptr(sums), _lib.ptr(sums_g), C, float(count), _lib.ptr(dbeta), _lib.ptr(dgamma),
+                                      _lib.ptr(kk), _lib.stream()), "facl_bn_bwd_consts")
+    return dbeta, dgamma, kk
+
+
 def _forward_bn_consts(y, bn, training, reduce_fn, ws, sums=None):
     """Statistics -> (5,C) constants; updates running stats / num_batches_tracked in training mode."""
     R, C = y.shape
@@ -114,12 +125,7 @@ class _LinearBNReLU(torch.autograd.Function):
         sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
         _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws),
                                            _lib.stream()), "facl_rows_bwd_stats")
-        sl = sums.float()                                               # parameter gradients stay local sums
-        dbeta, dgamma = sl[:, 0], sl[:, 1]
-        if ctx.reduce_fn is not None:
-            ctx.reduce_fn(sums)
-            sl = sums.float()
-        kk = (sl.t() * (1.0 / ctx.count)).contiguous()                  # (2,C): dbeta/P, dgamma/P
+        dbeta, dgamma, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)   # parameter gradients stay local sums
         dy = torch.empty_like(y)
         _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                            _lib.stream()), "facl_rows_bwd_apply")
@@ -170,12 +176,7 @@ class _LinearBNSegmax(torch.autograd.Function):
         _lib.check(lib.facl_segmax_bwd_stats(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
                    "facl_segmax_bwd_stats")
-        sl = sums.float()
-        dbeta, dgamma = sl[:, 0], sl[:, 1]
-        if ctx.reduce_fn is not None:
-            ctx.reduce_fn(sums)
-            sl = sums.float()
-        kk = (sl.t() * (1.0 / ctx.count)).contiguous()
+        dbeta, dgamma, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)   # parameter gradients stay local sums
         dy = torch.empty_like(y)
         _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), _lib.stream()),

@@ -134,6 +134,10 @@ int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nu
  *   facl_sa_bwd_consts2  sums1 (dbeta2,dgamma2) -> bw2 (4,64) for facl_sa_bwd2
  *   facl_sa_bwd_final    all partial sums -> dW3,dgamma3,dbeta3, dW2,dgamma2,dbeta2, dW1,dgamma1,dbeta1
  *                        (R1_g (8,64) = all-reduced tail of facl_sa_bwd2's output, mom_l = local x moments) */
+/* BN backward constants of a row layer (tail): sums (C,2) = (dbeta, dgamma) of THIS rank / after the SyncBN
+ * all-reduce -> dbeta (C), dgamma (C) fp32 parameter gradients (local) and kk (2,C) = reduced sums / P */
+int facl_bn_bwd_consts(const double* sums_local, const double* sums_global, int C, double P, float* dbeta,
+                       float* dgamma, float* kk, void* stream);
 int facl_sa_bwd_consts3(const double* sums0, const float* bnc3, const float* W3, const float* b3, double P,
                         float* G3, float* h3, void* stream);
 int facl_sa_bwd_consts2(const double* sums1, const float* bnc2, double P, float* bw2, void* stream);

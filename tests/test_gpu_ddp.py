@@ -83,3 +83,38 @@ def test_two_ranks_equal_single_process_global_batch():
             assert np.linalg.norm(g2 - g1) <= 2e-4 * max(np.linalg.norm(g1), 1e-2 * gmax) + 1e-6, (k, r)
     for k, b1 in bufs1.items():                                   # SyncBN: running statistics of the GLOBAL batch
         assert np.allclose(res[0][3][k], b1.numpy(), rtol=2e-5, atol=1e-7), k
+
+
+def _worker_nccl1(port, q):
+    """Real RCCL backend with a 1-rank group: every collective of facl_amd/dist.py executes (fp64 all-reduce of the BN
+    buffers, all-gather + reduce-scatter of the embeddings, flat gradient all-reduce) and must be the identity."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    from facl_amd import dist as fdist
+    import facl_amd.train_common as TC
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    fdist.is_distributed = lambda: True                          # is_distributed() is world_size > 1: force the hooks on
+    TC.fdist.is_distributed = fdist.is_distributed
+    torch.manual_seed(3)
+    full = torch.rand(4, 4, 512, 4) - 0.5
+    loss, grads, bufs = _run_step(full, 4, 0, 1)
+    q.put((loss, {k: v.numpy() for k, v in grads.items()}))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_group_is_identity():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl1, args=(29700 + (os.getpid() % 2000), q))
+    p.start()
+    loss_d, grads_d = q.get(timeout=300)
+    p.join(timeout=60)
+    torch.manual_seed(3)
+    full = torch.rand(4, 4, 512, 4) - 0.5
+    loss1, grads1, _ = _run_step(full, 4, 0, 1)
+    assert abs(loss1 - loss_d) <= 1e-6 * abs(loss1)
+    for k, g1 in grads1.items():
+        g1 = g1.numpy()
+        assert np.linalg.norm(grads_d[k] - g1) <= 1e-5 * max(np.linalg.norm(g1), 1e-6), k

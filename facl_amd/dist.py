@@ -103,3 +103,75 @@ def allreduce_gradients(params, group=None):
     else:
         for g, v in zip(grads, views):
             g.copy_(v)
+
+
+class GradSync:
+    """Gradient averaging with the big bucket overlapped with the rest of the backward.
+
+    99 % of the 2.36 M parameters sit in the tail (net3DV_3 / netR_FC), whose gradients are complete before the
+    set-abstraction backward (2 ms of kernels) starts.  Post-accumulate hooks count the tail parameters; when the
+    last one has its gradient the flat bucket is all-reduced ASYNCHRONOUSLY (RCCL runs it on its own stream) and
+    `finish()` -- called after backward -- reduces the small remainder, waits, scales and copies back.  The first
+    step runs fully synchronous and records which parameters receive gradients at all (e.g. `mapping.weight` does not).
+    """
+
+    def __init__(self, named_params, group=None, early_prefixes=("net3DV_3.", "netR_FC.")):
+        self.group = group
+        self.named = [(k, p) for k, p in named_params if p.requires_grad]
+        self.early_prefixes = early_prefixes
+        self.early = None              # parameters of the overlapped bucket (known after the first step)
+        self.late = None
+        self.pending = 0
+        self.work = None
+        self.flat = None
+        self.handles = []
+
+    def _arm(self):
+        self.pending = len(self.early)
+        self.work, self.flat = None, None
+
+    def _hook(self, _p):
+        self.pending -= 1
+        if self.pending == 0:
+            grads = [p.grad for p in self.early]
+            self.flat = torch.cat([g.reshape(-1) for g in grads])
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def _scatter_back(flat, grads, world):
+        flat.div_(world)
+        views, o = [], 0
+        for g in grads:
+            views.append(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        if hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_(grads, views)
+        else:
+            for g, v in zip(grads, views):
+                g.copy_(v)
+
+    def finish(self):
+        """Call after loss.backward(): every parameter gradient is the average over the ranks afterwards."""
+        if not is_distributed():
+            return
+        world = dist.get_world_size(self.group)
+        if self.early is None:                                   # first step: synchronous, learn the buckets
+            allreduce_gradients([p for _, p in self.named], self.group)
+            with_grad = [(k, p) for k, p in self.named if p.grad is not None]
+            self.early = [p for k, p in with_grad if k.startswith(self.early_prefixes)]
+            self.late = [p for k, p in with_grad if not k.startswith(self.early_prefixes)]
+            if self.early and hasattr(self.early[0], "register_post_accumulate_grad_hook"):
+                self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.early]
+            else:
+                self.late, self.early = self.early + self.late, []
+            self._arm()
+            return
+        if self.late:
+            allreduce_gradients(self.late, self.group)
+        if self.early:
+            if self.work is None:                                # a hook did not fire (unexpected): stay correct
+                allreduce_gradients(self.early, self.group)
+            else:
+                self.work.wait()
+                self._scatter_back(self.flat, [p.grad for p in self.early], world)
+        self._arm()

@@ -78,6 +78,7 @@ class ContrastiveStep:
         self.r2 = group_radius
         self.fps_reorder = fps_reorder
         self.rank = torch.distributed.get_rank() if fdist.is_distributed() else 0
+        self.grad_sync = fdist.GradSync(list(netR.named_parameters())) if fdist.is_distributed() else None
 
     def group(self, data1):
         opt = self.opt
@@ -115,7 +116,8 @@ class ContrastiveStep:
         loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        fdist.allreduce_gradients(netR.parameters())
+        if self.grad_sync is not None:
+            self.grad_sync.finish()                                                # tail bucket overlapped with the SA backward
         self.optimizer.step()
         return loss, loss_c, loss_circle
 

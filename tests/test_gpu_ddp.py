@@ -33,6 +33,9 @@ def _run_step(clip, G, rank, world):
     net.bn_reduce_fn = fdist.make_bn_reduce_fn()
     optim = torch.optim.SGD(net.parameters(), lr=0.0)            # keep the parameters: we compare gradients
     step = ContrastiveStep(net, optim, opt, G)
+    # two steps (lr = 0): the first gradient sync is synchronous and learns the buckets, the second one overlaps the
+    # tail bucket's all-reduce with the set-abstraction backward (facl_amd/dist.py: GradSync)
+    step(clip.cuda(), epoch=0, order=np.array([2, 0, 3, 1]))
     loss, _, _ = step(clip.cuda(), epoch=0, order=np.array([2, 0, 3, 1]))
     grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
     bufs = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k}

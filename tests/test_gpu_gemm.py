@@ -73,3 +73,34 @@ def test_gemm_wgrad(M, N, K, nz):
                                    _lib.stream()), "wgrad")
     ref = dy.double().t() @ a.double()
     assert rel_err(dW.cpu().numpy(), ref.cpu().numpy()) < 3e-6
+
+
+@pytest.mark.parametrize("K,N,ctr", [(256, 256, True), (256, 512, False), (512, 1024, False)])
+def test_tail_layers_headline_size_vs_torch_fp64(K, N, ctr):
+    """The three net3DV_3 layers at the headline row count (B*T*S = 49,152 centroid rows) through the Python wrappers the
+    encoder uses (forward + fused BN statistics [+ centre term], dgrad, split-K wgrad with the production slice count)
+    against fp64 matmuls on the GPU; the error must stay at fp32-GEMM level (rocBLAS sgemm sits at 3-4e-7 here)."""
+    from facl_amd import tail
+    M = 49152
+    g = torch.Generator(device=DEV).manual_seed(K + N)
+    a = torch.relu(torch.randn(M, K, device=DEV, generator=g))            # post-ReLU activations: half zeros
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    cen = torch.randn(M, 3, device=DEV, generator=g) if ctr else None
+    Wc = torch.randn(N, 3, device=DEV, generator=g).contiguous() if ctr else None
+    dy = torch.randn(M, N, device=DEV, generator=g) * 1e-3
+    y, sums = tail.gemm_fwd(a, W, b, want_stats=True, centers=cen, Wc=Wc)
+    ref = a.double() @ W.double().t() + b.double()
+    if ctr:
+        ref = ref + cen.double() @ Wc.double().t()
+    assert float((y.double() - ref).norm() / ref.norm()) < 6e-7
+    assert float((sums[:, 0] - ref.sum(0)).abs().max() / ref.abs().sum(0).max()) < 1e-6
+    assert float(((sums[:, 1] - (ref * ref).sum(0)).abs() / (ref * ref).sum(0)).max()) < 1e-6
+    del ref, y
+    da = tail.gemm_dgrad(dy, W)
+    ref = dy.double() @ W.double()
+    assert float((da.double() - ref).norm() / ref.norm()) < 6e-7
+    del ref, da
+    dW = tail.gemm_wgrad(dy, a)
+    ref = dy.double().t() @ a.double()
+    assert float((dW.double() - ref).norm() / ref.norm()) < 2e-6          # 49,152-term sums, slices added in fp32

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
             const double s = st.x + __shfl_xor(st.x, 32, 64);
             const double sq = st.y + __shfl_xor(st.y, 32, 64);
             if (h == 0) {
-                part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = s;
+                part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = s * (double)sgn3[32 * ct3 + q];   // statistics of y3, not of sgn3*y3
                 part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = sq;
             }
         }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
 #pragma unroll
         for (int ct3 = 0; ct3 < 8; ++ct3) {
             const double2 st = stat[ct3 * 32 + q];
-            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x;
+            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x * (double)sgn3[32 * ct3 + q];   // statistics of y3, not of sgn3*y3
             part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = st.y;
         }
     }

@@ -27,6 +27,16 @@ class _Workspace:
         return cls._ws[key]
 
 
+_PM1 = {}
+
+
+def _plus_minus_one(dev):
+    key = (dev.type, dev.index)
+    if key not in _PM1:
+        _PM1[key] = (torch.tensor(-1.0, dtype=torch.float32, device=dev), torch.tensor(1.0, dtype=torch.float32, device=dev))
+    return _PM1[key]
+
+
 def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM):
     lib = _lib.load_library()
     bnc = torch.empty((5, C), dtype=torch.float32, device=sums.device)
@@ -129,7 +139,7 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
             _running_update(bnc2, p["rm2"], p["rv2"], n_true)
     else:
         bnc2 = _bn_eval(64, p["g2"], p["be2"], p["rm2"], p["rv2"])
-    sgn3 = torch.where(p["g3"] < 0, -1.0, 1.0).to(torch.float32)
+    sgn3 = torch.where(p["g3"] < 0, *_plus_minus_one(dev))           # sign(gamma3) with sign(0) = +1
     ymax = torch.empty((nunits, 256), dtype=torch.float32, device=dev)
     arg = torch.empty((nunits, 256), dtype=torch.uint8, device=dev)
     sums3 = torch.empty((256, 2), **f64) if training else None
@@ -139,8 +149,6 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     if training:
         if reduce_fn is not None:
             reduce_fn(sums3)
-        # statistics were taken of sgn3*y3: flip the channel sums back (sum of squares is unchanged)
-        sums3[:, 0] *= sgn3.double()
         rm, rv = (p["rm3"], p["rv3"]) if direct else (None, None)
         bnc3 = _bn_finalize(sums3, 256, count, p["g3"], p["be3"], rm, rv)
         if update_running and not direct:

@@ -125,6 +125,20 @@ def circle_contrast(num_crop, x, batchSize, criterion=None, order=None, x_keys=N
 
 
 # ---- fused HIP path for both losses (csrc/loss.hip): 2 library GEMMs + one kernel per loss ------------
+_POSCOL_CACHE = {}
+
+
+def _positive_columns(G, B, Bk, clip_offset, dev):
+    """(n_idx (B,), pos_g (G*B,)) int32: this rank's clip columns and the positive column of every (view, clip) slot of
+    the global loss.  They only depend on the shapes, so they are built once (6 tiny launches per step otherwise)."""
+    key = (G, B, Bk, clip_offset, dev.type, dev.index)
+    if key not in _POSCOL_CACHE:
+        n_idx = torch.arange(B, device=dev, dtype=torch.int32) + clip_offset
+        g_idx = torch.arange(G, device=dev, dtype=torch.int32)
+        _POSCOL_CACHE[key] = (n_idx, (g_idx[:, None] * Bk + n_idx[None, :]).reshape(-1).contiguous())
+    return _POSCOL_CACHE[key]
+
+
 class _ContrastiveLosses(torch.autograd.Function):
     """(loss_c, loss_circle) with the value and d/dsim computed by facl_contrast; the similarity GEMMs and
     their transposes in the backward are plain library GEMMs."""
@@ -143,9 +157,7 @@ class _ContrastiveLosses(torch.autograd.Function):
         keys = x_keys.contiguous()
         xv = x.view(G, B, C)
         anchors = xv[order[:-1]].reshape((G - 1) * B, C).contiguous()              # circle anchors (:100,:103)
-        n_idx = torch.arange(B, device=dev, dtype=torch.int32) + clip_offset
-        g_idx = torch.arange(G, device=dev, dtype=torch.int32)
-        pos_g = (g_idx[:, None] * Bk + n_idx[None, :]).reshape(-1)                  # global: sim_g is (B,J); slots = views
+        n_idx, pos_g = _positive_columns(G, B, Bk, clip_offset, dev)                 # global: sim_g is (B,J); slots = views
         pos_c = (order[1:].to(torch.int32)[:, None] * Bk + n_idx[None, :]).reshape(-1).contiguous()
         sim_c = anchors @ keys.t()                                                 # ((G-1)B, J)  :103
         sim_g = xg @ keys.t()                                                      # (B, J)       :71
@@ -153,7 +165,7 @@ class _ContrastiveLosses(torch.autograd.Function):
         dsim_c = torch.empty_like(sim_c)
         out = torch.empty(2, dtype=torch.float64, device=dev)
         st = _lib.stream()
-        _lib.check(lib.facl_contrast(_lib.ptr(sim_g), B, J, B, Bk, 1, G, 0, _lib.ptr(pos_g.contiguous()), clip_offset,
+        _lib.check(lib.facl_contrast(_lib.ptr(sim_g), B, J, B, Bk, 1, G, 0, _lib.ptr(pos_g), clip_offset,
                                      _lib.ptr(dsim_g), out[0:1].data_ptr(), _lib.ptr(ws), st), "facl_contrast(global)")
         _lib.check(lib.facl_contrast(_lib.ptr(sim_c), (G - 1) * B, J, B, Bk, G - 1, G - 1, 1, _lib.ptr(pos_c), clip_offset,
                                      _lib.ptr(dsim_c), out[1:2].data_ptr(), _lib.ptr(ws), st), "facl_contrast(circle)")

@@ -89,7 +89,7 @@ int facl_bn_eval_consts(int C, const float* gamma, const float* beta, const floa
  *   facl_sa_fwd2                x -> y2 = relu(bn1(y1)) W2^T + b2, stored in "fragment layout"
  *                               (nunits*4096 floats, see csrc/common.h); sums2 (64,2) or NULL
  *   facl_sa_fwd3                y2 -> per (group,channel) max_k sgn3*y3 and its argmax k (uint8),
- *                               y3 = relu(bn2(y2)) W3^T + b3; sums3 (256,2) of sgn3*y3 or NULL
+ *                               y3 = relu(bn2(y2)) W3^T + b3; sums3 (256,2) = (sum, sumsq) of y3 or NULL
  *   facl_sa_pool                pooled = relu(|scale3| * ymax + shift3)   (rows,C)
  */
 int facl_sa_x_moments(const float* x, int64_t P, int D, double* mom, void* ws, void* stream);

@@ -52,19 +52,6 @@ def make_opt(a):
                            pooling="concatenation", SAMPLE_NUM=a.N)
 
 
-def _time_launch(launch, st, iters=10, warm=3):
-    """Average launch duration (ms) from HIP events recorded on the stream the kernel is launched on."""
-    for _ in range(warm):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        launch()
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
 def _pmc_traffic(a, kernel):
     # HBM bytes per launch: PMC counters are collected offline (rocprofv3 --pmc, profiles/pmc_traffic.json) at this
     # exact shape; reported only when the shape matches, else null.
@@ -77,63 +64,45 @@ def _pmc_traffic(a, kernel):
     return None
 
 
-def dominant_kernel_roofline(a, dev):
-    """Live timing (HIP events on the launch stream) of the three heaviest kernels of the step on synthetic operands of
-    the step's shapes.  `roofline` is the single longest kernel, k_sa_bwd1 (HBM-side: it streams y2 in and dz2 out,
-    its MFMA part is small); `roofline_more` carries the two MFMA kernels (k_sa_fwd3_sb and the largest k_gemm_sb),
-    priced against the bf16 MFMA peak with the bf16 FLOPs they EXECUTE (6 per fp32 multiply-add)."""
+def dominant_kernel_roofline(a, eager_step, batches, nsteps=8):
+    """Average duration of the three heaviest kernels measured INSIDE the training step: `nsteps` extra eager steps
+    (after the timed region) with HIP events recorded on the launch stream around the three launches
+    (facl_amd/_lib.py: timed).  `roofline` is the single longest kernel, k_sa_bwd1 (HBM-side: it streams y2 in and dz2
+    out, its MFMA part is small); `roofline_more` carries the two MFMA kernels (k_sa_fwd3_sb and the largest
+    k_gemm_sb), priced against the bf16 MFMA peak with the bf16 FLOPs they EXECUTE (6 per fp32 multiply-add, see
+    DESIGN.md).  The brackets include the two ~5 us partial-sum reduction launches that follow each of these kernels
+    inside its C entry point."""
     from facl_amd import _lib
-    from facl_amd.sa_mlp import _Workspace
-    lib, p = _lib.load_library(), _lib.ptr
     nunits = a.B * a.T * 64
-    f32, f64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float64, device=dev)
-    y2f = torch.randn(nunits * 4096, **f32)
-    sc, sh = torch.rand(64, **f32) + 0.5, torch.randn(64, **f32) * 0.1
-    W3, b3 = torch.randn(256, 64, **f32) * 0.1, torch.randn(256, **f32) * 0.1
-    sgn = torch.ones(256, **f32)
-    ymax = torch.empty(nunits, 256, **f32)
-    arg = torch.randint(0, 64, (nunits, 256), dtype=torch.uint8, device=dev)
-    sums3, sums1 = torch.empty(256, 2, **f64), torch.empty(64, 2, **f64)
-    ws = _Workspace.get(dev)
-    st = torch.cuda.current_stream()
-    s_ = st.cuda_stream
-
+    M, K, N = nunits, 512, 1024
+    glabel = "facl_gemm_fwd %dx%dx%d" % (M, K, N)
+    _lib.TIMING = {"facl_sa_bwd1": [], "facl_sa_fwd3": [], glabel: []}
+    try:
+        for i in range(nsteps):
+            eager_step(batches[i % 2], epoch=0)
+        ms1, ms3, msg = _lib.timing_ms("facl_sa_bwd1"), _lib.timing_ms("facl_sa_fwd3"), _lib.timing_ms(glabel)
+    finally:
+        _lib.TIMING = None
     # ---- k_sa_bwd1: y2 (16 KiB/unit) + coef (1 KiB) + arg (256 B) in, dz2 (16 KiB) out
-    bnc2 = torch.stack([torch.zeros(64, **f32), torch.ones(64, **f32), sc, sh, torch.zeros(64, **f32)]).contiguous()
-    G3, h3 = torch.randn(64, 64, **f32) * 0.01, torch.randn(64, **f32) * 0.01
-    coef = torch.randn(nunits, 256, **f32)
-    dz2f = torch.empty_like(y2f)
-    ms1 = _time_launch(lambda: _lib.check(lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg),
-                                                         p(dz2f), p(sums1), p(ws), s_), "facl_sa_bwd1"), st)
     bytes1 = float(nunits) * (2 * 16384 + 1024 + 256)
     ach1 = bytes1 / (ms1 * 1e-3) / 1e9
     main = {"kernel": "k_sa_bwd1", "bound": "hbm", "achieved": round(ach1, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(ach1 / PEAK_HBM_GBPS, 4), "traffic": _pmc_traffic(a, "k_sa_bwd1"),
-            "ms_per_launch": round(ms1, 4), "algorithmic_bytes_per_launch": bytes1}
-    del dz2f, coef
-
+            "ms_per_launch": round(ms1, 4), "algorithmic_bytes_per_launch": bytes1, "measured": "in-step, %d steps" % nsteps}
     # ---- k_sa_fwd3_sb: 64 -> 256 layer of the SA-MLP, 2*64*256 FLOP per position (SURVEY 8d), x6 bf16 MFMA FLOPs
-    ms3 = _time_launch(lambda: _lib.check(lib.facl_sa_fwd3(p(y2f), nunits, p(sc), p(sh), p(W3), p(b3), p(sgn), p(ymax),
-                                                         p(arg), p(sums3), p(ws), s_), "facl_sa_fwd3"), st)
     fl3 = 2.0 * 64 * 256 * nunits * 64
     more = [{"kernel": "k_sa_fwd3_sb", "bound": "mfma", "achieved": round(6 * fl3 / (ms3 * 1e-3) / 1e12, 1),
              "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(6 * fl3 / (ms3 * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4),
              "traffic": _pmc_traffic(a, "k_sa_fwd3_sb"), "ms_per_launch": round(ms3, 4), "algorithmic_flops_per_launch": fl3,
              "algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * fl3}]
-    del y2f, ymax
-
     # ---- largest tail GEMM (net3DV_3.6: 512 -> 1024 over the M*S centroid rows), forward
-    M, K, N = a.B * a.T * 64, 512, 1024
-    x, W, bias = torch.randn(M, K, **f32), torch.randn(N, K, **f32) * 0.05, torch.zeros(N, **f32)
-    y, gs = torch.empty(M, N, **f32), torch.empty(N, 2, **f64)
-    msg = _time_launch(lambda: _lib.check(lib.facl_gemm_fwd(p(x), M, K, p(W), K, N, p(bias), None, None, None, None, 0, p(y),
-                                                          p(gs), p(ws), s_), "facl_gemm_fwd"), st)
-    flg = 2.0 * M * K * N
-    more.append({"kernel": "k_gemm_sb<KC,KC> 49152x512x1024", "bound": "mfma", "achieved": round(6 * flg / (msg * 1e-3) / 1e12, 1),
-                 "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(6 * flg / (msg * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
-                 "ms_per_launch": round(msg, 4), "algorithmic_flops_per_launch": flg,
-                 "algorithmic_tflops": round(flg / (msg * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * flg})
+    if msg is not None:
+        flg = 2.0 * M * K * N
+        more.append({"kernel": "k_gemm_sb<KC,KC> %dx%dx%d" % (M, K, N), "bound": "mfma",
+                     "achieved": round(6 * flg / (msg * 1e-3) / 1e12, 1), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(6 * flg / (msg * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
+                     "ms_per_launch": round(msg, 4), "algorithmic_flops_per_launch": flg,
+                     "algorithmic_tflops": round(flg / (msg * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * flg})
     return main, more
 
 
@@ -181,6 +150,7 @@ def main():
     use_graph = bool(a.graph) and world == 1
     optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, capturable=use_graph, fused=True)
     step = ContrastiveStep(net, optim, opt, a.T, fps_reorder=bool(a.fps))
+    eager_step = step
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]   # resident in HBM
@@ -212,6 +182,8 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.item())
 
+    # in-step kernel timing: extra eager steps on EVERY rank (they contain the collectives), reported by rank 0
+    rl_main, rl_more = dominant_kernel_roofline(a, eager_step, batches)
     out = None
     if rank == 0:
         clips = a.B * world * a.steps / dt
@@ -223,7 +195,7 @@ def main():
                                       f"cn3d_model_conbag encoder, global+circle loss, backward, Adam",
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode},
                "final_loss": final_loss}
-        out["roofline"], out["roofline_more"] = dominant_kernel_roofline(a, dev)
+        out["roofline"], out["roofline_more"] = rl_main, rl_more
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
     if world > 1:

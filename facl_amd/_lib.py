@@ -107,3 +107,38 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("facl_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+
+
+# ---- optional in-step kernel timing (bench.py's roofline section) ----------------------------------------------------
+# When TIMING is a dict {label: []}, `timed(label)` brackets the launches issued inside the `with` block with HIP
+# events on the launch stream (eager execution only: events cannot be recorded inside a graph replay).
+TIMING = None
+
+
+class timed:
+    def __init__(self, label):
+        self.on = TIMING is not None and label in TIMING
+        self.label = label
+
+    def __enter__(self):
+        if self.on:
+            import torch
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            import torch
+            self.e1.record(torch.cuda.current_stream())
+            TIMING[self.label].append((self.e0, self.e1))
+        return False
+
+
+def timing_ms(label):
+    """Average milliseconds of the recorded brackets of `label` (synchronises)."""
+    evs = TIMING[label]
+    if not evs:
+        return None
+    evs[-1][1].synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / len(evs)

@@ -143,9 +143,10 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     ymax = torch.empty((nunits, 256), dtype=torch.float32, device=dev)
     arg = torch.empty((nunits, 256), dtype=torch.uint8, device=dev)
     sums3 = torch.empty((256, 2), **f64) if training else None
-    _lib.check(lib.facl_sa_fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
-                                _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
-                                _lib.ptr(ws), st), "facl_sa_fwd3")
+    with _lib.timed("facl_sa_fwd3"):
+        _lib.check(lib.facl_sa_fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
+                                    _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
+                                    _lib.ptr(ws), st), "facl_sa_fwd3")
     if training:
         if reduce_fn is not None:
             reduce_fn(sums3)
@@ -213,8 +214,9 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     # ---- pass 1: dz2 + (dbeta2, dgamma2)
     dz2f = torch.empty_like(ctx["y2f"])
     sums1 = torch.empty((64, 2), **f64)
-    _lib.check(lib.facl_sa_bwd1(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(G3), ptr(h3), ptr(W3), ptr(coef), ptr(ctx["arg"]),
-                                ptr(dz2f), ptr(sums1), ptr(ws), st), "facl_sa_bwd1")
+    with _lib.timed("facl_sa_bwd1"):
+        _lib.check(lib.facl_sa_bwd1(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(G3), ptr(h3), ptr(W3), ptr(coef),
+                                    ptr(ctx["arg"]), ptr(dz2f), ptr(sums1), ptr(ws), st), "facl_sa_bwd1")
     sums1_l = sums1
     if reduce_fn is not None:
         sums1 = reduce_fn(sums1.clone())

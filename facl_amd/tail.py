@@ -20,9 +20,10 @@ def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
     y = torch.empty((M, N), dtype=torch.float32, device=a.device)
     sums = torch.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
     ws = _Workspace.get(a.device)
-    _lib.check(lib.facl_gemm_fwd(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
-                                 _lib.ptr(centers), _lib.ptr(Wc), 3 if Wc is not None else 0, _lib.ptr(y),
-                                 _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_gemm_fwd")
+    with _lib.timed("facl_gemm_fwd %dx%dx%d" % (M, K, N)):
+        _lib.check(lib.facl_gemm_fwd(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
+                                     _lib.ptr(centers), _lib.ptr(Wc), 3 if Wc is not None else 0, _lib.ptr(y),
+                                     _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_gemm_fwd")
     return y, sums
 
 

@@ -168,16 +168,13 @@ class PointNet_Plus(nn.Module):
         # gobaol_max_pool over all gost*S local features of a clip (:225-226) = max over the gost views of
         # the per-view maxima (rows are view-major: g*B+b)
         xg_pre = x_pre.view(self.gost, Bc, 1024).max(dim=0).values
-        x = self._fc(x_pre, training)                                          # :228
-        x_global = self._fc(xg_pre, training)                                  # :229 (second BN statistics update)
+        # :228 x = netR_FC(x_pre), :229 x_global = netR_FC(x_global_pre): one pass over the two Linear layers for both,
+        # BatchNorm statistics (and the two running-statistics updates) per call like the reference
+        fc = self.netR_FC
+        x, x_global = _tail.fc_head(x_pre, xg_pre, fc[0], fc[1], fc[3], training, self.bn_reduce_fn)
         x_nor = F.normalize(x, p=2, dim=1)                                     # :231
         code = F.linear(x_nor, self.mapping.weight)                            # :232
         return x, code, x_nor, x_global
-
-    def _fc(self, v, training):
-        fc = self.netR_FC
-        v = _tail.linear_bn_relu(v, fc[0], fc[1], training, self.bn_reduce_fn)
-        return _tail.linear(v, fc[3])
 
 
 class PointNet_Plus_fine(PointNet_Plus):

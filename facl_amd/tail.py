@@ -210,6 +210,73 @@ class _Linear(torch.autograd.Function):
         return gemm_dgrad(dy, W), gemm_wgrad(dy, h), dy.sum(0)
 
 
+class _FCHead(torch.autograd.Function):
+    """netR_FC (Linear -> BatchNorm1d -> ReLU -> Linear, cn3d_model_conbag.py:201-207) applied to the per-view rows AND
+    to the per-clip rows (:228-229) in one pass: the two Linear layers run ONCE on the stacked rows (the second call has
+    only B rows -- 16 workgroups for a 1024x1024 layer, latency-bound), while BatchNorm keeps the reference's two
+    separate batch statistics and its two sequential running-statistics updates, segment by segment."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, W1, b1, gamma, beta, bn, W2, b2, training, reduce_fn):
+        lib = _lib.load_library()
+        _lib.require_cuda(xa, xb)
+        ws = _Workspace.get(xa.device)
+        h = torch.cat((xa, xb), dim=0)
+        W1, W2 = W1.contiguous(), W2.contiguous()
+        y, _ = gemm_fwd(h, W1, b1)
+        R, C = y.shape
+        segs = ((0, xa.shape[0]), (xa.shape[0], R))
+        a = torch.empty_like(y)
+        bncs, counts = [], []
+        for r0, r1 in segs:                                  # first the view rows, then the clip rows (:228, :229)
+            ys = y[r0:r1]
+            bnc, count = _forward_bn_consts(ys, bn, training, reduce_fn, ws)
+            _lib.check(lib.facl_rows_bn_relu(_lib.ptr(ys), r1 - r0, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a[r0:r1]),
+                                             _lib.stream()), "facl_rows_bn_relu")
+            bncs.append(bnc)
+            counts.append(count)
+        out, _ = gemm_fwd(a, W2, b2)
+        ctx.save_for_backward(h, W1, y, a, W2, *bncs)
+        ctx.segs, ctx.counts, ctx.reduce_fn, ctx.training = segs, counts, reduce_fn, training
+        return out[:segs[0][1]], out[segs[0][1]:]
+
+    @staticmethod
+    def backward(ctx, da_out, db_out):
+        if not ctx.training:
+            raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
+        lib = _lib.load_library()
+        h, W1, y, a, W2, bnc_a, bnc_b = ctx.saved_tensors
+        ws = _Workspace.get(y.device)
+        R, C = y.shape
+        dout = torch.cat((da_out, db_out), dim=0)
+        dW2 = gemm_wgrad(dout, a)
+        db2 = dout.sum(0)
+        dact = gemm_dgrad(dout, W2)
+        dy = torch.empty_like(y)
+        dgamma = dbeta = None
+        for (r0, r1), bnc, count in zip(ctx.segs, (bnc_a, bnc_b), ctx.counts):
+            n = r1 - r0
+            sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+            _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), n, C, _lib.ptr(bnc), _lib.ptr(sums),
+                                               _lib.ptr(ws), _lib.stream()), "facl_rows_bwd_stats")
+            dbe, dga, kk = _bn_bwd_consts(sums, C, count, ctx.reduce_fn)
+            _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), n, C, _lib.ptr(bnc), _lib.ptr(kk),
+                                               _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
+            dgamma = dga if dgamma is None else dgamma + dga
+            dbeta = dbe if dbeta is None else dbeta + dbe
+        dW1 = gemm_wgrad(dy, h)
+        dh = gemm_dgrad(dy, W1)
+        na = ctx.segs[0][1]
+        # d(bias of the first Linear) is identically zero in front of a train-mode BN: None leaves it untouched
+        return dh[:na], dh[na:], dW1, None, dgamma, dbeta, None, dW2, db2, None, None
+
+
+def fc_head(xa, xb, affine1, bn, affine2, training, reduce_fn=None):
+    """(netR_FC(xa), netR_FC(xb)) with the reference's two BatchNorm calls and ONE pass over each Linear layer."""
+    return _FCHead.apply(xa, xb, affine1.weight, affine1.bias, bn.weight, bn.bias, bn, affine2.weight, affine2.bias,
+                         training, reduce_fn)
+
+
 def linear(h, affine):
     return _Linear.apply(h, affine.weight, affine.bias)
 

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_sa_bwd_consts3(const double* __restrict
                                                         const float* __restrict__ W3, const float* __restrict__ b3,
                                                         double P, float* __restrict__ G3, float* __restrict__ h3) {
     __shared__ double g[256], hc[256];
+    __shared__ float w3s[256 * 64];                      // W3 staged once per block: the 256-term dots read LDS, not L2
     const int c = threadIdx.x;
     {
         const double mean = bnc3[c], inv = bnc3[256 + c], sc = bnc3[512 + c];
@@ -184,17 +185,19 @@ __global__ __launch_bounds__(256) void k_sa_bwd_consts3(const double* __restrict
         g[c] = gg;
         hc[c] = -(sc * sums0[2 * c]) / P + gg * ((double)b3[c] - mean);
     }
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        reinterpret_cast<float4*>(w3s)[i] = reinterpret_cast<const float4*>(W3)[i];
     __syncthreads();
     const int o = blockIdx.x * 256 + threadIdx.x;       // 0..4095: G3[k][j]; 4096..4159: h3[j]
     if (o < 4096) {
         const int k = o >> 6, j = o & 63;
         double s = 0;
-        for (int cc = 0; cc < 256; ++cc) s += g[cc] * (double)W3[cc * 64 + k] * (double)W3[cc * 64 + j];
+        for (int cc = 0; cc < 256; ++cc) s += g[cc] * (double)w3s[cc * 64 + k] * (double)w3s[cc * 64 + j];
         G3[o] = (float)s;
     } else if (o < 4160) {
         const int j = o - 4096;
         double s = 0;
-        for (int cc = 0; cc < 256; ++cc) s += hc[cc] * (double)W3[cc * 64 + j];
+        for (int cc = 0; cc < 256; ++cc) s += hc[cc] * (double)w3s[cc * 64 + j];
         h3[j] = (float)s;
     }
 }

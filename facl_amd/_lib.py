@@ -44,6 +44,7 @@ SIGNATURES = {
     "facl_segmax_bwd_stats": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "facl_segmax_bwd_apply": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_gemm_fwd_segmax": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_wgrad": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "facl_contrast": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],

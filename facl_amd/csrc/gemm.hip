@@ -38,6 +38,9 @@ struct GemmArgs {
     const float* xa; const float* xb; int ldxb;  // rank-3 extra term: C += xa[i][0..2] . xb[j][0..2]  (or null)
     double* part;                      // column statistics partials [(MI/64)][NJ][2], or null
     int kchunk;                        // split-K: k range per blockIdx.z (wgrad); C then is [z][MI][NJ]
+    // fused max over each block of 64 consecutive rows (my_max_pool over the S = 64 centroids of a cloud): per
+    // (row block, column) max of sgn[j]*C and the FIRST row that attains it; 128x128 tiles only.  Null when unused.
+    const float* sgn; float* smax; int* sarg;
 };
 
 template <int LAY, int T>
@@ -131,6 +134,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
         float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
         if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
         float s = 0.f, sq = 0.f;
+        const float sg = (g.smax && jin) ? g.sgn[j] : 1.f;
+        float best = 0.f;
+        int bp = 0;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -142,7 +148,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
                     v = fmaf(g.xa[(size_t)i * 3], xb0, fmaf(g.xa[(size_t)i * 3 + 1], xb1, fmaf(g.xa[(size_t)i * 3 + 2], xb2, v)));
                 stg[il * SP + 32 * b + q] = v;
                 if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
+                if (TM == 2 && g.smax) {
+                    const float sv = sg * v;
+                    if ((a == 0 && r == 0) || sv > best) { best = sv; bp = 32 * a + rowmap(r, 0); }
+                }
             }
+        if (TM == 2 && g.smax) {                                           // the wave tile's 64 rows = one cloud
+            bp += 4 * h;
+            const float ob = __shfl_xor(best, 32, 64);
+            const int op = __shfl_xor(bp, 32, 64);
+            if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }   // first max wins (MaxPool2d)
+            if (h == 0 && jin) {
+                const size_t o = (size_t)((i0 + WR * wr) >> 6) * g.NJ + j;
+                g.smax[o] = best;
+                g.sarg[o] = bp;
+            }
+        }
         if (g.part) {
             const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
             if (h == 0 && jin) {
@@ -646,7 +667,7 @@ extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, i
     if ((pscale == nullptr) != (pshift == nullptr) || (centers == nullptr) != (Wc == nullptr)) return FACL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, pscale, pshift, centers, Wc, ldwc,
-               sums ? (double*)ws : nullptr, K};
+               sums ? (double*)ws : nullptr, K, nullptr, nullptr, nullptr};
     int rpp = 64;
     int rc = pscale ? launch<KC, KC, true>(g, 1, st, &rpp) : launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
@@ -657,12 +678,32 @@ extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, i
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
 }
 
+// facl_gemm_fwd + my_max_pool over blocks of S = 64 consecutive rows fused into the epilogue: ymax (M/64,N) =
+// max_s sgn[j]*y, arg = first s that attains it (BN + ReLU are monotone per channel, so the pooled activation follows
+// from ymax once the statistics are final: facl_sa_pool).  Saves the 201 MB re-read of y by facl_rows_segmax.
+extern "C" int facl_gemm_fwd_segmax(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                                    const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                                    void* stream) {
+    if (!a || !W || !y || !sgn || !ymax || !arg || (sums && !ws)) return FACL_E_NULL;
+    if (M < 64 || M > 0x7fffffff || (M & 63) || K < 4 || (K & 3) || N < 1 || (ldw & 3)) return FACL_E_SHAPE;
+    if ((long long)((N + 127) / 128) * ((M + 127) / 128) < 256) return FACL_E_CONFIG;    // needs the 128x128 tiles
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, nullptr, nullptr, nullptr, nullptr, 0,
+               sums ? (double*)ws : nullptr, K, sgn, ymax, arg};
+    int rpp = 64;
+    int rc = launch<KC, KC, false>(g, 1, st, &rpp);
+    if (rc || !sums) return rc;
+    const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
+    if ((size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
+}
+
 // da (M,K) = dy (M,N) W (N,K)        (W row-major with leading dimension ldw; pass W + offset to skip columns)
 extern "C" int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
                                void* stream) {
     if (!dy || !W || !da) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 1) return FACL_E_SHAPE;
-    GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N};
+    GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N, nullptr, nullptr, nullptr};
     return launch<KC, IC, false>(g, 1, (hipStream_t)stream, nullptr);
 }
 
@@ -675,7 +716,7 @@ extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N
     int kchunk = (int)((M + nz - 1) / nz);
     kchunk = (kchunk + BK - 1) / BK * BK;
     nz = (int)((M + kchunk - 1) / kchunk);
-    GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk};
+    GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr};
     int rc = launch<IC, IC, false>(g, nz, st, nullptr);
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;

@@ -8,7 +8,7 @@ matching backward passes are the row kernels of csrc/rows.hip.
 import torch
 
 from . import _lib
-from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
+from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize, _plus_minus_one
 
 
 def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
@@ -149,14 +149,33 @@ class _LinearBNSegmax(torch.autograd.Function):
         ws = _Workspace.get(h.device)
         h = h.contiguous()
         W = W.contiguous()
-        y, sums = gemm_fwd(h, W, b, want_stats=training)
-        bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
-        R, C = y.shape
+        R, C = h.shape[0], W.shape[0]
         M = R // S
-        xpre = torch.empty((M, C), dtype=torch.float32, device=y.device)
-        arg = torch.empty((M, C), dtype=torch.int32, device=y.device)
-        _lib.check(lib.facl_rows_segmax(_lib.ptr(y), M, S, C, _lib.ptr(bnc), _lib.ptr(xpre), _lib.ptr(arg), _lib.stream()),
-                   "facl_rows_segmax")
+        xpre = torch.empty((M, C), dtype=torch.float32, device=h.device)
+        arg = torch.empty((M, C), dtype=torch.int32, device=h.device)
+        fused = False
+        if S == 64 and R % 64 == 0:
+            # max over the 64 centroid rows of each cloud inside the GEMM epilogue (sign(gamma) is known before the
+            # statistics are; BN + ReLU are monotone per channel): y is not re-read by a pooling pass
+            sgn = torch.where(gamma.detach() < 0, *_plus_minus_one(h.device))
+            y = torch.empty((R, C), dtype=torch.float32, device=h.device)
+            sums = torch.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
+            ymax = torch.empty((M, C), dtype=torch.float32, device=h.device)
+            rc = lib.facl_gemm_fwd_segmax(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b), _lib.ptr(sgn),
+                                          _lib.ptr(y), _lib.ptr(sums), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(ws),
+                                          _lib.stream())
+            if rc == 0:
+                fused = True
+                bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
+                _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(xpre),
+                                            _lib.stream()), "facl_sa_pool")
+            elif rc != -4:                                   # FACL_E_CONFIG: too small for the fused kernel
+                _lib.check(rc, "facl_gemm_fwd_segmax")
+        if not fused:
+            y, sums = gemm_fwd(h, W, b, want_stats=training)
+            bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
+            _lib.check(lib.facl_rows_segmax(_lib.ptr(y), M, S, C, _lib.ptr(bnc), _lib.ptr(xpre), _lib.ptr(arg),
+                                            _lib.stream()), "facl_rows_segmax")
         ctx.save_for_backward(h, W, y, bnc, xpre, arg)
         ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
         ctx.mark_non_differentiable(arg)

@@ -29,6 +29,7 @@ extern "C" {
 #define FACL_E_SHAPE  (-1)   /* unsupported shape (see each function)            */
 #define FACL_E_NULL   (-2)   /* a required pointer is NULL                       */
 #define FACL_E_ALIGN  (-3)   /* a pointer is not aligned as the kernel requires  */
+#define FACL_E_CONFIG (-4)   /* the fused variant does not cover this size: use the unfused entry points */
 
 /* Library / ABI version: (major << 16) | minor. */
 int facl_version(void);
@@ -182,6 +183,13 @@ int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y,
 int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
                   const float* pscale, const float* pshift, const float* centers, const float* Wc,
                   int ldwc, float* y, double* sums, void* ws, void* stream);
+/* facl_gemm_fwd with my_max_pool over blocks of S = 64 consecutive rows fused into its epilogue
+ * (cn3d_model_conbag.py:71-73 + :80/:199): ymax (M/64,N) = max over the block of sgn[j]*y, arg (M/64,N) = first row of
+ * the block that attains it.  FACL_E_CONFIG when the problem is too small for the 128x128-tile kernel (callers then use
+ * facl_gemm_fwd + facl_rows_segmax). */
+int facl_gemm_fwd_segmax(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                         const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                         void* stream);
 int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
                     void* stream);
 int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,

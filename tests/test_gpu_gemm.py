@@ -104,3 +104,35 @@ def test_tail_layers_headline_size_vs_torch_fp64(K, N, ctr):
     dW = tail.gemm_wgrad(dy, a)
     ref = dy.double().t() @ a.double()
     assert float((dW.double() - ref).norm() / ref.norm()) < 2e-6          # 49,152-term sums, slices added in fp32
+
+
+def test_gemm_fwd_segmax_fused_epilogue():
+    """facl_gemm_fwd_segmax: y, BN sums, and per (64-row block, column) max of sgn*y with the FIRST argmax (ties included)."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    M, K, N = 64 * 512, 64, 1024                                        # 256 x 8 tiles of 128x128: the fused kernel applies
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    a[64:128] = a[64:65]                                                # a whole block of identical rows: exact ties
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    sgn = torch.where(torch.rand(N, device=DEV, generator=g) < 0.5, -1.0, 1.0)
+    y = torch.empty(M, N, device=DEV)
+    sums = torch.empty(N, 2, dtype=torch.float64, device=DEV)
+    ymax = torch.empty(M // 64, N, device=DEV)
+    arg = torch.empty(M // 64, N, dtype=torch.int32, device=DEV)
+    p = _lib.ptr
+    _lib.check(lib.facl_gemm_fwd_segmax(p(a), M, K, p(W), K, N, p(b), p(sgn), p(y), p(sums), p(ymax), p(arg), p(_ws()),
+                                        _lib.stream()), "gemm_fwd_segmax")
+    ref = a.double() @ W.double().t() + b.double()
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert rel_err(sums[:, 1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-5
+    sy = (y * sgn).view(M // 64, 64, N)                                 # the kernel's own fp32 y: max / argmax are exact
+    want, _ = sy.max(dim=1)
+    assert torch.equal(ymax, want)
+    first = (sy == want.unsqueeze(1)).int().argmax(dim=1).int()          # first row attaining the max
+    assert torch.equal(arg, first)
+    assert int(arg[1].max()) == 0                                        # the all-ties block resolves to row 0
+    # too small for the 128x128-tile kernel: the entry point says so and launches nothing
+    assert lib.facl_gemm_fwd_segmax(p(a), 128, K, p(W), K, 256, p(b), p(sgn), p(y), None, p(ymax), p(arg), p(_ws()),
+                                    _lib.stream()) == -4

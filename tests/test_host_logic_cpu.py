@@ -159,3 +159,27 @@ def test_world_size_2_gloo_sharded_loss_equals_global():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_line.json (the last bench.py line measured on an MI355X) carries every field of the driver's
+    contract plus the roofline / cpu_baseline objects; bench.py itself needs a GPU and is run by the driver."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")

@@ -102,3 +102,20 @@ def test_linear_probe_consumes_extracted_feature_format():
     ref = torch.nn.functional.linear(torch.nn.functional.normalize(feats[:7].double(), dim=1), model.fc.weight.double(),
                                      model.fc.bias.double())
     assert torch.allclose(model(feats[:7]).double(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_appearance_entry_checkpoint_name_and_extract(tmp_path):
+    """BASELINE configs[2]: the appearance stream = same model / kernels / loss through cn3d_train_apperance_GL's entry
+    (branch '1', checkpoint corr_GL_appereance_<epoch>.pth, :341) and extract_apperance_feature."""
+    from facl_amd import cn3d_train_apperance_GL as train, extract_apperance_feature as ext
+    from oracle.weights import state_dict_shapes
+    ck = str(tmp_path / "ck")
+    train.main(["--batchSize", "3", "--nepoch", "1", "--steps_per_epoch", "1", "--num_crop", "4", "--SAMPLE_NUM", "512",
+                "--save_root_dir", ck, "--INPUT_FEATURE_NUM", "4"])
+    path = os.path.join(ck, "corr_GL_appereance_0.pth")
+    assert os.path.exists(path)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == [k for k, _ in state_dict_shapes(4)]
+    feats = ext.main(["--checkpoint", path, "--batchSize", "2", "--num_crop", "4", "--SAMPLE_NUM", "512",
+                      "--INPUT_FEATURE_NUM", "4", "--num_batches", "1", "--save_path", str(tmp_path / "f")])
+    assert feats.shape == (2, 5 * 512) and np.isfinite(feats).all()

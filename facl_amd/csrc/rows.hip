@@ -94,6 +94,28 @@ __global__ void k_rows_bwd_apply(const float* __restrict__ dout, const float* __
     }
 }
 
+// the same, 4 channels per lane (C % 4 == 0, 16-byte aligned tensors): one (row, channel-quad) per iteration
+__global__ __launch_bounds__(256) void k_rows_bwd_apply4(const float* __restrict__ dout, const float* __restrict__ y,
+                                                         int R, int C4, const float* __restrict__ bnc,
+                                                         const float* __restrict__ kk, float* __restrict__ dy) {
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    if (c4 >= C4) return;
+    const int C = 4 * C4;
+    const float4 mean = reinterpret_cast<const float4*>(bnc)[c4], inv = reinterpret_cast<const float4*>(bnc + C)[c4];
+    const float4 scale = reinterpret_cast<const float4*>(bnc + 2 * C)[c4], shift = reinterpret_cast<const float4*>(bnc + 3 * C)[c4];
+    const float4 k1 = reinterpret_cast<const float4*>(kk)[c4], k2 = reinterpret_cast<const float4*>(kk + C)[c4];
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+        const size_t o = (size_t)r * C4 + c4;
+        const float4 v = reinterpret_cast<const float4*>(y)[o], g = reinterpret_cast<const float4*>(dout)[o];
+        float4 out;
+        out.x = scale.x * ((fmaf(scale.x, v.x, shift.x) > 0.f ? g.x : 0.f) - k1.x - (v.x - mean.x) * inv.x * k2.x);
+        out.y = scale.y * ((fmaf(scale.y, v.y, shift.y) > 0.f ? g.y : 0.f) - k1.y - (v.y - mean.y) * inv.y * k2.y);
+        out.z = scale.z * ((fmaf(scale.z, v.z, shift.z) > 0.f ? g.z : 0.f) - k1.z - (v.z - mean.z) * inv.z * k2.z);
+        out.w = scale.w * ((fmaf(scale.w, v.w, shift.w) > 0.f ? g.w : 0.f) - k1.w - (v.w - mean.w) * inv.w * k2.w);
+        reinterpret_cast<float4*>(dy)[o] = out;
+    }
+}
+
 // ---- backward through the max over S (+ BN + ReLU): sparse sums, then the dense dy -----------------
 // dz[m,c] = dxpre[m,c] * [xpre > 0] lives at row arg[m,c]; yhat there = (y_at_arg - mean)*inv.
 __global__ __launch_bounds__(256) void k_segmax_bwd_stats(const float* __restrict__ dxpre, const float* __restrict__ xpre,
@@ -132,6 +154,35 @@ __global__ __launch_bounds__(256) void k_segmax_bwd_apply(const float* __restric
     for (int s = 0; s < S; ++s) {
         const float v = yb[(size_t)s * C];
         db[(size_t)s * C] = scale * ((s == a ? d : 0.f) - k1 - (v - mean) * inv * k2);
+    }
+}
+
+// the same, 4 channels per lane (C % 4 == 0, 16-byte aligned tensors)
+__global__ __launch_bounds__(256) void k_segmax_bwd_apply4(const float* __restrict__ dxpre, const float* __restrict__ xpre,
+                                                           const float* __restrict__ y, const int* __restrict__ arg,
+                                                           int S, int C4, const float* __restrict__ bnc,
+                                                           const float* __restrict__ kk, float* __restrict__ dy) {
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (c4 >= C4) return;
+    const int C = 4 * C4;
+    const float4 mean = reinterpret_cast<const float4*>(bnc)[c4], inv = reinterpret_cast<const float4*>(bnc + C)[c4];
+    const float4 scale = reinterpret_cast<const float4*>(bnc + 2 * C)[c4];
+    const float4 k1 = reinterpret_cast<const float4*>(kk)[c4], k2 = reinterpret_cast<const float4*>(kk + C)[c4];
+    const size_t o = (size_t)m * C4 + c4;
+    const float4 xp = reinterpret_cast<const float4*>(xpre)[o], dx = reinterpret_cast<const float4*>(dxpre)[o];
+    const int4 a = reinterpret_cast<const int4*>(arg)[o];
+    const float4 d = make_float4(xp.x > 0.f ? dx.x : 0.f, xp.y > 0.f ? dx.y : 0.f, xp.z > 0.f ? dx.z : 0.f, xp.w > 0.f ? dx.w : 0.f);
+    const float4* yb = reinterpret_cast<const float4*>(y) + (size_t)m * S * C4 + c4;
+    float4* db = reinterpret_cast<float4*>(dy) + (size_t)m * S * C4 + c4;
+    for (int s = 0; s < S; ++s) {
+        const float4 v = yb[(size_t)s * C4];
+        float4 out;
+        out.x = scale.x * ((s == a.x ? d.x : 0.f) - k1.x - (v.x - mean.x) * inv.x * k2.x);
+        out.y = scale.y * ((s == a.y ? d.y : 0.f) - k1.y - (v.y - mean.y) * inv.y * k2.y);
+        out.z = scale.z * ((s == a.z ? d.z : 0.f) - k1.z - (v.z - mean.z) * inv.z * k2.z);
+        out.w = scale.w * ((s == a.w ? d.w : 0.f) - k1.w - (v.w - mean.w) * inv.w * k2.w);
+        db[(size_t)s * C4] = out;
     }
 }
 
@@ -192,6 +243,13 @@ extern "C" int facl_rows_bwd_apply(const float* dout, const float* y, int64_t R,
                                    const float* kk, float* dy, void* stream) {
     if (!dout || !y || !bnc || !kk || !dy) return FACL_E_NULL;
     if (R < 1 || C < 1) return FACL_E_SHAPE;
+    if (!(C & 3) && R <= 0x7fffffff && !((((uintptr_t)dout) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)bnc) | ((uintptr_t)kk)) & 15)) {
+        const int gx = (C / 4 + 255) / 256;
+        int gy = 4096 / gx;
+        if (gy > R) gy = (int)R;
+        hipLaunchKernelGGL(k_rows_bwd_apply4, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dout, y, (int)R, C / 4, bnc, kk, dy);
+        return facl_launch_status();
+    }
     const long long n = R * (long long)C;
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_rows_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, y, n, C, bnc, kk, dy);
@@ -216,6 +274,12 @@ extern "C" int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, cons
                                      void* stream) {
     if (!dxpre || !xpre || !y || !arg || !bnc || !kk || !dy) return FACL_E_NULL;
     if (M < 1 || M > 65535 || S < 1 || C < 1) return FACL_E_SHAPE;
+    if (!(C & 3) && !((((uintptr_t)dxpre) | ((uintptr_t)xpre) | ((uintptr_t)y) | ((uintptr_t)arg) | ((uintptr_t)dy) |
+                       ((uintptr_t)bnc) | ((uintptr_t)kk)) & 15)) {
+        hipLaunchKernelGGL(k_segmax_bwd_apply4, dim3((C / 4 + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, dxpre,
+                           xpre, y, arg, S, C / 4, bnc, kk, dy);
+        return facl_launch_status();
+    }
     hipLaunchKernelGGL(k_segmax_bwd_apply, dim3((C + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, dxpre,
                        xpre, y, arg, S, C, bnc, kk, dy);
     return facl_launch_status();

@@ -101,6 +101,69 @@ __global__ __launch_bounds__(256) void k_contrast(const float* __restrict__ sim,
     if (threadIdx.x == 0) part[n] = loss * (double)invB;
 }
 
+// The same computation with 1024 threads per clip and the clip's nA x J similarities held in registers between the
+// passes (one read of sim, no per-element integer modulo in the inner passes): the grid is only B workgroups, so the
+// kernel is latency-bound and three streaming passes with 256 threads took 65 us for the circle loss at H.
+constexpr int CK = 24;                      // cached values per thread: nA*J <= 24*1024
+
+__global__ __launch_bounds__(1024) void k_contrast_reg(const float* __restrict__ sim, int J, int B, int Bk, int nA, int nS,
+                                                      int slot_rows, const int* __restrict__ poscol, int clip_offset,
+                                                      float* __restrict__ dsim, double* __restrict__ part) {
+    __shared__ float smf[16];
+    __shared__ double smd[16];
+    const int n = blockIdx.x;
+    const int myclip = n + clip_offset;
+    const int total = nA * J;
+    float v[CK];
+    float mx = 0.f;                                        // masked entries are 0, there is at least one
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const int e = threadIdx.x + k * 1024;
+        float x = 0.f;                                     // beyond the end: behaves like a masked column
+        if (e < total) {
+            const int i = e / J, j = e - i * J;
+            x = (j % Bk == myclip) ? 0.f : sim[(size_t)(i * B + n) * J + j];
+        }
+        v[k] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = block_reduce_max(mx, smf);
+    double se = 0;
+#pragma unroll
+    for (int k = 0; k < CK; ++k)
+        if (threadIdx.x + k * 1024 < total) se += (double)__expf(v[k] - mx);
+    se = block_reduce_sum(se, smd);
+    const float lse = mx + (float)log(se);
+    // per-slot terms, one slot per thread (the serial loop of k_contrast is nS dependent load pairs per thread)
+    double loss_t = 0, dlse_t = 0;
+    float dpos = 0.f;
+    size_t ppos = 0;
+    const float invB = 1.f / (float)B;
+    for (int s = threadIdx.x; s < nS; s += 1024) {       // nS <= 1024 in every use: at most one trip per thread
+        const int r = (slot_rows ? s : 0) * B + n;
+        ppos = (size_t)r * J + poscol[s * B + n];
+        const float pos = sim[ppos];
+        const float m2 = fmaxf(pos, lse);
+        const float t = m2 + log1pf(__expf(-fabsf(pos - lse)));
+        loss_t += (double)(t - pos);
+        dlse_t += (double)(1.f - __expf(pos - t));
+        dpos = (__expf(pos - t) - 1.f) * invB;
+    }
+    const double loss = block_reduce_sum(loss_t, smd);
+    const float dlse = (float)block_reduce_sum(dlse_t, smd) * invB;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const int e = threadIdx.x + k * 1024;
+        if (e < total) {
+            const int i = e / J, j = e - i * J;
+            dsim[(size_t)(i * B + n) * J + j] = (j % Bk == myclip) ? 0.f : dlse * __expf(v[k] - lse);
+        }
+    }
+    __syncthreads();                                       // the positives overwrite zeros written just above
+    if (threadIdx.x < nS) dsim[ppos] = dpos;
+    if (threadIdx.x == 0) part[n] = loss * (double)invB;
+}
+
 }  // namespace
 
 extern "C" int facl_contrast(const float* sim, int R, int J, int B, int Bk, int nA, int nS, int slot_rows,
@@ -110,8 +173,12 @@ extern "C" int facl_contrast(const float* sim, int R, int J, int B, int Bk, int 
     if (B < 1 || nA < 1 || nS < 1 || R != nA * B || J < 1 || Bk < 1 || J % Bk) return FACL_E_SHAPE;
     if (slot_rows && nS != nA) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_contrast, dim3(B), dim3(256), 0, st, sim, J, B, Bk, nA, nS, slot_rows, poscol, clip_offset,
-                       dsim, (double*)ws);
+    if ((long long)nA * J <= (long long)CK * 1024 && nS <= 1024)
+        hipLaunchKernelGGL(k_contrast_reg, dim3(B), dim3(1024), 0, st, sim, J, B, Bk, nA, nS, slot_rows, poscol, clip_offset,
+                           dsim, (double*)ws);
+    else
+        hipLaunchKernelGGL(k_contrast, dim3(B), dim3(256), 0, st, sim, J, B, Bk, nA, nS, slot_rows, poscol, clip_offset,
+                           dsim, (double*)ws);
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, B, 1, loss, st);

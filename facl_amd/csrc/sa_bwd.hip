@@ -40,23 +40,43 @@ constexpr int TQ = 65;    // padded row of a tile accessed with b32 only (confli
 __global__ __launch_bounds__(256) void k_sa_bwd0(const float* __restrict__ dpooled, const float* __restrict__ ymax,
                                                  int rows, const float* __restrict__ bnc3,
                                                  float* __restrict__ coef, double* __restrict__ part) {
-    const int c = threadIdx.x;
-    const float mean = bnc3[c], invstd = bnc3[256 + c], scale = bnc3[512 + c], shift = bnc3[768 + c],
-                sgn = bnc3[1024 + c];
-    const float ascale = fabsf(scale);
-    double db = 0, dg = 0;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-        const float ym = ymax[(size_t)r * 256 + c];
-        const float dp = dpooled[(size_t)r * 256 + c];
-        const float z = fmaf(ascale, ym, shift);
-        const float dz = z > 0.f ? dp : 0.f;
-        const float yhat = (sgn * ym - mean) * invstd;
-        coef[(size_t)r * 256 + c] = scale * dz;
-        db += (double)dz;
-        dg += (double)dz * (double)yhat;
+    // block = 64 channel quads (16 B per lane) x 4 row phases; the phases are combined through LDS so that a block
+    // writes ONE partial row of 512 doubles
+    __shared__ double red[3][64][8];
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const float4 mean = reinterpret_cast<const float4*>(bnc3)[lane], invstd = reinterpret_cast<const float4*>(bnc3 + 256)[lane];
+    const float4 scale = reinterpret_cast<const float4*>(bnc3 + 512)[lane], shift = reinterpret_cast<const float4*>(bnc3 + 768)[lane];
+    const float4 sgn = reinterpret_cast<const float4*>(bnc3 + 1024)[lane];
+    const float mn[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
+    const float sc[4] = {scale.x, scale.y, scale.z, scale.w}, sh[4] = {shift.x, shift.y, shift.z, shift.w};
+    const float sg[4] = {sgn.x, sgn.y, sgn.z, sgn.w};
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = blockIdx.x * 4 + ph; r < rows; r += gridDim.x * 4) {
+        const float4 ym4 = reinterpret_cast<const float4*>(ymax)[(size_t)r * 64 + lane];
+        const float4 dp4 = reinterpret_cast<const float4*>(dpooled)[(size_t)r * 64 + lane];
+        const float ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w}, dp[4] = {dp4.x, dp4.y, dp4.z, dp4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(fabsf(sc[e]), ym[e], sh[e]);
+            const float dz = z > 0.f ? dp[e] : 0.f;
+            const float yhat = (sg[e] * ym[e] - mn[e]) * iv[e];
+            o[e] = sc[e] * dz;
+            acc[2 * e] += (double)dz;
+            acc[2 * e + 1] += (double)dz * (double)yhat;
+        }
+        reinterpret_cast<float4*>(coef)[(size_t)r * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
     }
-    part[(size_t)blockIdx.x * 512 + 2 * c] = db;
-    part[(size_t)blockIdx.x * 512 + 2 * c + 1] = dg;
+    if (ph > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[ph - 1][lane][e] = acc[e];
+    }
+    __syncthreads();
+    if (ph == 0) {
+        double* pr = part + (size_t)blockIdx.x * 512 + 8 * lane;          // channels 4*lane..4*lane+3, (dbeta, dgamma) pairs
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pr[e] = ((acc[e] + red[0][lane][e]) + red[1][lane][e]) + red[2][lane][e];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

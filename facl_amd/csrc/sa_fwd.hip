@@ -188,6 +188,162 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2(const float* __restrict__ x,
     }
 }
 
+// Split-bf16 (bf16x6, common.h) version of fwd2: same orientation, outputs and statistics; W2's A fragments are
+// pre-split planes in LDS (24 KiB), the lane computes layer 1 for its two positions on exactly the 32 channels its
+// k-slots need (block kk, half h, slot j <-> channel 16kk + 8h + j) and splits them in registers.  96 MFMAs per unit
+// instead of 128 four-times-slower ones: the kernel becomes bound by its 16 KiB/unit store stream.
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__ x, int nunits,
+                                                       const float* __restrict__ l1tab_g, const float* __restrict__ W2,
+                                                       const float* __restrict__ b2, float* __restrict__ y2f,
+                                                       double* __restrict__ part) {
+    __shared__ uint4 w2p[2 * 4 * 3 * 64];   // A fragments of W2, [(rt*4 + kk)*3 + plane][lane]: W2[32rt+r][16kk+8h .. +7]
+    __shared__ float4 l1tab[64 * 2];        // folded layer 1: [c][w0 w1 w2 w3 | b 0 0 0]
+    __shared__ float4 b2s[16];
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int ln = i & 63, kk = (i >> 6) & 3, rt = i >> 8;
+        const float* wrow = W2 + (32 * rt + (ln & 31)) * 64 + 16 * kk + 8 * (ln >> 5);
+        const float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 4);
+        unsigned hi[4], mi[4], lo[4];
+        split_pair(w0.x, w0.y, hi[0], mi[0], lo[0]);
+        split_pair(w0.z, w0.w, hi[1], mi[1], lo[1]);
+        split_pair(w1.x, w1.y, hi[2], mi[2], lo[2]);
+        split_pair(w1.z, w1.w, hi[3], mi[3], lo[3]);
+        uint4* d = w2p + ((rt * 4 + kk) * 3) * 64 + ln;
+        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    if (threadIdx.x < 128) l1tab[threadIdx.x] = reinterpret_cast<const float4*>(l1tab_g)[threadIdx.x];
+    if (threadIdx.x < 16) b2s[threadIdx.x] = reinterpret_cast<const float4*>(b2)[threadIdx.x];
+    __syncthreads();
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+
+    float ps[2][16], pq[2][16];            // per-lane partial sum / sumsq of y2, channel = 32rt+rowmap(r,h)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ps[rt][r] = 0.f; pq[rt][r] = 0.f; }
+
+    auto load_x = [&](int u, float (&xv)[2][4]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const size_t p = (size_t)u * 64 + 32 * ct + q;
+            if (D == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(x + p * 4);
+                xv[ct][0] = t.x; xv[ct][1] = t.y; xv[ct][2] = t.z; xv[ct][3] = t.w;
+            } else {
+                xv[ct][0] = x[p * 3]; xv[ct][1] = x[p * 3 + 1]; xv[ct][2] = x[p * 3 + 2]; xv[ct][3] = 0.f;
+            }
+        }
+    };
+    float xn[2][4];
+    if (wave_g < nunits) load_x(wave_g, xn);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        asm volatile("" ::: "memory");       // LDS tables are re-read per unit instead of living in registers
+        float xv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[ct][i] = xn[ct][i];
+        if (u + nwaves < nunits) load_x(u + nwaves, xn);
+        // layer 1 on the VALU for this lane's two positions, straight into the bf16 planes of the B operand
+        bf16x8 ap[2][4][3];                  // [position tile][k16 block][plane]
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a1[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * kk + 8 * h + j;
+                const float4 w = l1tab[c * 2];
+                const float b = l1tab[c * 2 + 1].x;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    float v = fmaf(w.x, xv[ct][0], b);
+                    v = fmaf(w.y, xv[ct][1], v);
+                    v = fmaf(w.z, xv[ct][2], v);
+                    if (D == 4) v = fmaf(w.w, xv[ct][3], v);
+                    a1[ct][j] = fmaxf(v, 0.f);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) split_pair(a1[ct][2 * t], a1[ct][2 * t + 1], hi[t], mi[t], lo[t]);
+                ap[ct][kk][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
+                ap[ct][kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
+                ap[ct][kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+            }
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 bb = b2s[8 * rt + 2 * r4 + h];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[rt][ct][4 * r4 + 0] = bb.x; acc[rt][ct][4 * r4 + 1] = bb.y;
+                    acc[rt][ct][4 * r4 + 2] = bb.z; acc[rt][ct][4 * r4 + 3] = bb.w;
+                }
+            }
+        constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 wf[2][3];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[rt][pl] = __builtin_bit_cast(bf16x8, w2p[((rt * 4 + kk) * 3 + pl) * 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = MFMA_BF16(wf[rt][PA[t]], ap[ct][kk][PB[t]], acc[rt][ct]);
+        }
+        float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 v = make_float4(acc[rt][ct][4 * r4], acc[rt][ct][4 * r4 + 1],
+                                                 acc[rt][ct][4 * r4 + 2], acc[rt][ct][4 * r4 + 3]);
+                    *reinterpret_cast<float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4) = v;
+                }
+        if (part) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v0 = acc[rt][0][r], v1 = acc[rt][1][r];
+                    ps[rt][r] += v0 + v1;
+                    pq[rt][r] = fmaf(v0, v0, fmaf(v1, v1, pq[rt][r]));
+                }
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double s = ps[rt][r], sq = pq[rt][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); sq += __shfl_xor(sq, o, 64); }
+                if (q == 0) {
+                    const int c = 32 * rt + rowmap(r, h);
+                    part[(size_t)wave_g * 128 + 2 * c] = s;
+                    part[(size_t)wave_g * 128 + 2 * c + 1] = sq;
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fwd3: normal orientation  D3[p][c3] = sum_k a2[p][k] W3'[c3][k]  (lane = channel, registers =
 // positions), so BN statistics and the max over the group's positions are in-lane reductions.
@@ -480,8 +636,14 @@ extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < 2 * SA_GRID * 4 ? (nunits + 3) / 4 : 2 * SA_GRID);   // 2 workgroups per CU
     double* part = sums2 ? (double*)ws : nullptr;
-    if (D == 4) hipLaunchKernelGGL((k_sa_fwd2<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
-    else hipLaunchKernelGGL((k_sa_fwd2<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+    static const int use_f32 = getenv("FACL_SA_F32") ? atoi(getenv("FACL_SA_F32")) : 0;     // exact-fp32 MFMA kernel instead
+    if (use_f32) {
+        if (D == 4) hipLaunchKernelGGL((k_sa_fwd2<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+        else hipLaunchKernelGGL((k_sa_fwd2<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+    } else {
+        if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+        else hipLaunchKernelGGL((k_sa_fwd2_sb<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+    }
     int rc = facl_launch_status();
     if (rc || !sums2) return rc;
     // waves beyond nunits never enter the loop and still write their (zero) rows

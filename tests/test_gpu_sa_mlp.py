@@ -253,9 +253,14 @@ def test_sa_ragged_unit_counts(nunits):
         y = h @ q[Wk].reshape(q[Wk].shape[0], -1).t() + q[bk]
         mean, var = y.mean(0), y.var(0, unbiased=False)
         h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * q[gk] + q[bek])
-    ref = h.view(nunits, K, 256).max(dim=1).values
+    ref, ref_arg = h.view(nunits, K, 256).max(dim=1)
     assert max_rel_rows(pooled.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 5e-5
     (ref * w.double()).sum().backward()
+    # a max-pool decision that differs from fp64 (two neighbours within fp32 rounding) re-routes a whole gradient row:
+    # without such flips the gradients must agree tightly, with them only to the flip floor
+    flips = int((pooled.grad_fn.c["arg"].long() != ref_arg).sum())
+    assert flips <= max(2, 1e-4 * ref_arg.numel())
+    tol = 2e-3 if flips == 0 else 2e-2
     gmax = max(float(q[k].grad.norm()) for k in q)
     for k, mine in zip(sa_mlp._PARAM_ORDER, params):
         if k in ("b1", "b2", "b3"):
@@ -263,4 +268,4 @@ def test_sa_ragged_unit_counts(nunits):
         g64 = q[k].grad
         err = float((mine.grad.double() - g64).norm())
         # tiny batches make train-mode BN ill-conditioned (64 positions at nunits = 1): scaled like the golden tests
-        assert err <= 2e-3 * max(float(g64.norm()), 1e-2 * gmax), (k, err, float(g64.norm()))
+        assert err <= tol * max(float(g64.norm()), 1e-2 * gmax), (k, err, float(g64.norm()), flips)

@@ -106,7 +106,7 @@ def dominant_kernel_roofline(a, eager_step, batches, nsteps=8):
     # ---- largest tail GEMM (net3DV_3.6: 512 -> 1024 over the M*S centroid rows), forward
     if msg is not None:
         flg = 2.0 * M * K * N
-        more.append({"kernel": "k_gemm_sb<KC,KC> %dx%dx%d" % (M, K, N), "bound": "mfma",
+        more.append({"kernel": "k_gemm_sb<KC,KC> %dx%dx%d (+ fused max over the 64 centroids)" % (M, K, N), "bound": "mfma",
                      "achieved": round(6 * flg / (msg * 1e-3) / 1e12, 1), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(6 * flg / (msg * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
                      "ms_per_launch": round(msg, 4), "algorithmic_flops_per_launch": flg,

@@ -161,9 +161,10 @@ class _LinearBNSegmax(torch.autograd.Function):
             y = torch.empty((R, C), dtype=torch.float32, device=h.device)
             sums = torch.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
             ymax = torch.empty((M, C), dtype=torch.float32, device=h.device)
-            rc = lib.facl_gemm_fwd_segmax(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b), _lib.ptr(sgn),
-                                          _lib.ptr(y), _lib.ptr(sums), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(ws),
-                                          _lib.stream())
+            with _lib.timed("facl_gemm_fwd %dx%dx%d" % (R, h.shape[1], C)):
+                rc = lib.facl_gemm_fwd_segmax(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b),
+                                              _lib.ptr(sgn), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(ymax), _lib.ptr(arg),
+                                              _lib.ptr(ws), _lib.stream())
             if rc == 0:
                 fused = True
                 bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)

@@ -443,9 +443,15 @@ __global__ __launch_bounds__(256) void k_sa_bwd2(const float* __restrict__ dz2f,
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
     const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    f32x16 dw2[2][2], r1[2];
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x16 dw2[2][2];
+    f32x4v r1[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dw2[0][0][r] = dw2[0][1][r] = dw2[1][0][r] = dw2[1][1][r] = 0.f; r1[0][r] = r1[1][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) dw2[0][0][r] = dw2[0][1][r] = dw2[1][0][r] = dw2[1][1][r] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r1[jt][r] = 0.f;
 
     for (int u = wave_g; u < nunits; u += nwaves) {
         asm volatile("" ::: "memory");
@@ -549,12 +555,19 @@ __global__ __launch_bounds__(256) void k_sa_bwd2(const float* __restrict__ dz2f,
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) T[(32 * ct + q) * TQ + 32 * ro + rowmap(r, h)] = dz1[ro][ct][r];
         WAVE_LDS_FENCE();
+        // R1 has only 8 useful rows: 16x16x4 tiles (rows = x_0..x_{D-1}, 1, zeros; 4 column tiles of 16 channels; 4 positions
+        // per instruction) do it in 64 x 32 cycles instead of 64 x 64 with 32-row tiles.
+        // lane l: A[row l&15][k = l>>4], B[k = l>>4][col l&15]; result col = l&15, row = 4*(l>>4) + reg
+        {
+            const int l15 = lane & 15, kq = lane >> 4;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const float xa = q < 8 ? xs[(32 * h + s) * 8 + q] : 0.f;
-            const float z0 = T[(32 * h + s) * TQ + q], z1 = T[(32 * h + s) * TQ + 32 + q];
-            r1[0] = MFMA32(xa, z0, r1[0]);
-            r1[1] = MFMA32(xa, z1, r1[1]);
+            for (int s = 0; s < 16; ++s) {
+                const int p = 4 * s + kq;
+                const float xa = l15 < 8 ? xs[p * 8 + l15] : 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    r1[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, T[p * TQ + 16 * jt + l15], r1[jt], 0, 0, 0);
+            }
         }
         WAVE_LDS_FENCE();      // next unit overwrites T / xs
     }
@@ -566,11 +579,11 @@ __global__ __launch_bounds__(256) void k_sa_bwd2(const float* __restrict__ dz2f,
 #pragma unroll
             for (int r = 0; r < 16; ++r) row[(32 * a + rowmap(r, h)) * 64 + 32 * b + q] = (double)dw2[a][b][r];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = rowmap(r, h);
-            if (d < 8) row[64 * 64 + d * 64 + 32 * b + q] = (double)r1[b][r];
+        for (int r = 0; r < 4; ++r) {
+            const int d = 4 * (lane >> 4) + r;
+            if (d < 8) row[64 * 64 + d * 64 + 16 * jt + (lane & 15)] = (double)r1[jt][r];
         }
 }
 

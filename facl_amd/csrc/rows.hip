@@ -222,6 +222,40 @@ __global__ __launch_bounds__(256) void k_segmax_bwd_apply4(const float* __restri
     }
 }
 
+// dWc[c][j] = sum_r dy[r][c] * centers[r][j]: the 3 centroid-xyz columns of the first per-centroid layer's weight
+// gradient (torch.cat((yt, xt), 1), cn3d_model_conbag.py:219).  A (C x 3) output is 97 % padding for a 128x128-tile
+// GEMM; this is one streaming pass over dy: block = 64 channel quads x 4 row phases, fp64 partial sums.
+__global__ __launch_bounds__(256) void k_rows_center_wgrad(const float* __restrict__ dy, const float* __restrict__ ctr,
+                                                           int R, int C4, double* __restrict__ part) {
+    __shared__ double red[3][64][12];
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c4 < C4) {
+        for (int r = blockIdx.y * 4 + ph; r < R; r += gridDim.y * 4) {
+            const float4 g = reinterpret_cast<const float4*>(dy)[(size_t)r * C4 + c4];
+            const float x0 = ctr[(size_t)r * 3], x1 = ctr[(size_t)r * 3 + 1], x2 = ctr[(size_t)r * 3 + 2];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[3 * e] += (double)gv[e] * (double)x0;
+                acc[3 * e + 1] += (double)gv[e] * (double)x1;
+                acc[3 * e + 2] += (double)gv[e] * (double)x2;
+            }
+        }
+    }
+    if (ph > 0) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) red[ph - 1][lane][e] = acc[e];
+    }
+    __syncthreads();
+    if (ph == 0 && c4 < C4) {
+        double* pr = part + (size_t)blockIdx.y * 12 * C4 + 12 * c4;      // (channel, xyz) row-major: 3*(4c4+e) + j
+#pragma unroll
+        for (int e = 0; e < 12; ++e) pr[e] = ((acc[e] + red[0][lane][e]) + red[1][lane][e]) + red[2][lane][e];
+    }
+}
+
 int rows_grid_y(int R, int C) {
     int gx = (C + 255) / 256;
     int gy = ROWS_BLOCKS / gx;
@@ -327,4 +361,20 @@ extern "C" int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, cons
     hipLaunchKernelGGL(k_segmax_bwd_apply, dim3((C + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, dxpre,
                        xpre, y, arg, S, C, bnc, kk, dy);
     return facl_launch_status();
+}
+
+extern "C" int facl_rows_center_wgrad(const float* dy, const float* centers, int64_t R, int C, double* dWc, void* ws,
+                                      void* stream) {
+    if (!dy || !centers || !dWc || !ws) return FACL_E_NULL;
+    if (R < 1 || R > 0x7fffffff || C < 4 || (C & 3) || 3 * C > 4608) return FACL_E_SHAPE;
+    if (((uintptr_t)dy) & 15) return FACL_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = (C / 4 + 63) / 64;
+    int gy = ROWS_BLOCKS / gx;
+    if (gy > (R + 3) / 4) gy = (int)((R + 3) / 4);
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(k_rows_center_wgrad, dim3(gx, gy), dim3(256), 0, st, dy, centers, (int)R, C / 4, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, gy, 3 * C, dWc, st);
 }

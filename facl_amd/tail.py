@@ -131,9 +131,11 @@ class _LinearBNReLU(torch.autograd.Function):
         _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                            _lib.stream()), "facl_rows_bwd_apply")
         dW = gemm_wgrad(dy, h)
-        if ctx.centers is not None:                                     # xyz columns (C,3): same kernel on a 4-wide pad
-            c4 = torch.nn.functional.pad(ctx.centers, (0, 1))
-            dW = torch.cat((gemm_wgrad(dy, c4)[:, :3], dW), dim=1)
+        if ctx.centers is not None:                                     # xyz columns (C,3): one streaming pass over dy
+            dWc = torch.empty((C, 3), dtype=torch.float64, device=y.device)
+            _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(ctx.centers), R, C, _lib.ptr(dWc), _lib.ptr(ws),
+                                                  _lib.stream()), "facl_rows_center_wgrad")
+            dW = torch.cat((dWc.float(), dW), dim=1)
         dh = gemm_dgrad(dy, ctx.Wh) if ctx.needs_input_grad[0] else None
         # d(bias) is identically zero in front of a train-mode BN: None leaves the parameter untouched
         return dh, dW, None, dgamma, dbeta, None, None, None, None

@@ -166,6 +166,10 @@ int facl_rows_segmax(const float* y, int64_t M, int S, int C, const float* bnc, 
                      void* stream);
 int facl_rows_bwd_stats(const float* dout, const float* y, int64_t R, int C, const float* bnc, double* sums,
                         void* ws, void* stream);
+/* dWc (C,3) fp64 = dy^T centers: the centroid-xyz columns of the first per-centroid layer's weight gradient
+ * (the input of net3DV_3 is torch.cat((yt, xt), 1), cn3d_model_conbag.py:219) in one streaming pass over dy */
+int facl_rows_center_wgrad(const float* dy, const float* centers, int64_t R, int C, double* dWc, void* ws,
+                           void* stream);
 int facl_rows_bwd_apply(const float* dout, const float* y, int64_t R, int C, const float* bnc,
                         const float* kk, float* dy, void* stream);
 int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,

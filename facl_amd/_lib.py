@@ -58,6 +58,8 @@ SIGNATURES = {
     "facl_sa_bwd_consts2": [c_p, c_p, c_d, c_p, c_p],
     "facl_bn_bwd_consts": [c_p, c_p, c_i, c_d, c_p, c_p, c_p, c_p],
     "facl_rows_center_wgrad": [c_p, c_p, c_l, c_i, c_p, c_p, c_p],
+    "facl_viewmax_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "facl_viewmax_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "facl_sa_bwd_final": [c_p] * 13 + [c_i, c_d] + [c_p] * 9 + [c_p],
 }
 RESTYPE_I64 = {"facl_ws_bytes"}

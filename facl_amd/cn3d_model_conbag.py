@@ -164,10 +164,9 @@ class PointNet_Plus(nn.Module):
         h = _tail.linear_bn_relu(h, self.net3DV_3[3], self.net3DV_3[4], training, self.bn_reduce_fn)
         # last layer fused with my_max_pool (:222-223): xt_local (M,1024,S,1) is never materialised post-BN
         x_pre = _tail.linear_bn_relu_segmax(h, self.net3DV_3[6], self.net3DV_3[7], training, S, self.bn_reduce_fn)
-        Bc = M // self.gost
         # gobaol_max_pool over all gost*S local features of a clip (:225-226) = max over the gost views of
         # the per-view maxima (rows are view-major: g*B+b)
-        xg_pre = x_pre.view(self.gost, Bc, 1024).max(dim=0).values
+        xg_pre = _tail.view_max(x_pre, self.gost)      # first view wins ties, like the reference's max-pool over the sequence
         # :228 x = netR_FC(x_pre), :229 x_global = netR_FC(x_global_pre): one pass over the two Linear layers for both,
         # BatchNorm statistics (and the two running-statistics updates) per call like the reference
         fc = self.netR_FC

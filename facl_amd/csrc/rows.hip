@@ -256,6 +256,39 @@ __global__ __launch_bounds__(256) void k_rows_center_wgrad(const float* __restri
     }
 }
 
+// ---- gobaol_max_pool (cn3d_model_conbag.py:225-226): max over the G views of a clip's per-view maxima -----------
+// x (G*B, C) view-major rows g*B+b -> out (B,C) = max_g, arg (B,C) = first g that attains it; 4 channels per lane.
+__global__ __launch_bounds__(256) void k_viewmax_fwd(const float* __restrict__ x, int G, int B, int C4,
+                                                     float* __restrict__ out, int* __restrict__ arg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (b, c4)
+    if (i >= B * C4) return;
+    const int b = i / C4, c4 = i - b * C4;
+    float4 best = reinterpret_cast<const float4*>(x)[(size_t)b * C4 + c4];
+    int4 bi = make_int4(0, 0, 0, 0);
+    for (int g = 1; g < G; ++g) {
+        const float4 v = reinterpret_cast<const float4*>(x)[((size_t)g * B + b) * C4 + c4];
+        if (v.x > best.x) { best.x = v.x; bi.x = g; }
+        if (v.y > best.y) { best.y = v.y; bi.y = g; }
+        if (v.z > best.z) { best.z = v.z; bi.z = g; }
+        if (v.w > best.w) { best.w = v.w; bi.w = g; }
+    }
+    reinterpret_cast<float4*>(out)[i] = best;
+    reinterpret_cast<int4*>(arg)[i] = bi;
+}
+
+// dx (G*B, C): dout routed to the winning view's row, zero elsewhere (every element written: no memset needed)
+__global__ __launch_bounds__(256) void k_viewmax_bwd(const float* __restrict__ dout, const int* __restrict__ arg, int G,
+                                                     int B, int C4, float* __restrict__ dx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C4) return;
+    const int b = i / C4, c4 = i - b * C4;
+    const float4 d = reinterpret_cast<const float4*>(dout)[i];
+    const int4 a = reinterpret_cast<const int4*>(arg)[i];
+    for (int g = 0; g < G; ++g)
+        reinterpret_cast<float4*>(dx)[((size_t)g * B + b) * C4 + c4] =
+            make_float4(a.x == g ? d.x : 0.f, a.y == g ? d.y : 0.f, a.z == g ? d.z : 0.f, a.w == g ? d.w : 0.f);
+}
+
 int rows_grid_y(int R, int C) {
     int gx = (C + 255) / 256;
     int gy = ROWS_BLOCKS / gx;
@@ -377,4 +410,22 @@ extern "C" int facl_rows_center_wgrad(const float* dy, const float* centers, int
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, gy, 3 * C, dWc, st);
+}
+
+extern "C" int facl_viewmax_fwd(const float* x, int G, int B, int C, float* out, int32_t* arg, void* stream) {
+    if (!x || !out || !arg) return FACL_E_NULL;
+    if (G < 1 || B < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)arg)) & 15) return FACL_E_ALIGN;
+    const int n = B * (C / 4);
+    hipLaunchKernelGGL(k_viewmax_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, G, B, C / 4, out, arg);
+    return facl_launch_status();
+}
+
+extern "C" int facl_viewmax_bwd(const float* dout, const int32_t* arg, int G, int B, int C, float* dx, void* stream) {
+    if (!dout || !arg || !dx) return FACL_E_NULL;
+    if (G < 1 || B < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
+    if ((((uintptr_t)dout) | ((uintptr_t)dx) | ((uintptr_t)arg)) & 15) return FACL_E_ALIGN;
+    const int n = B * (C / 4);
+    hipLaunchKernelGGL(k_viewmax_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, arg, G, B, C / 4, dx);
+    return facl_launch_status();
 }

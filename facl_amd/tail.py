@@ -299,6 +299,39 @@ def fc_head(xa, xb, affine1, bn, affine2, training, reduce_fn=None):
                          training, reduce_fn)
 
 
+class _ViewMax(torch.autograd.Function):
+    """gobaol_max_pool over the gost*S local features of a clip (cn3d_model_conbag.py:225-226) = max over the G views of
+    the per-view maxima (rows are view-major: g*B+b); first view wins ties, like the reference's MaxPool over the
+    concatenated sequence."""
+
+    @staticmethod
+    def forward(ctx, x_pre, G):
+        lib = _lib.load_library()
+        _lib.require_cuda(x_pre)
+        x_pre = x_pre.contiguous()
+        B, C = x_pre.shape[0] // G, x_pre.shape[1]
+        out = torch.empty((B, C), dtype=torch.float32, device=x_pre.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x_pre.device)
+        _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, C, _lib.ptr(out), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
+        ctx.save_for_backward(arg)
+        ctx.G = G
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load_library()
+        arg, = ctx.saved_tensors
+        B, C = arg.shape
+        dout = dout.contiguous()
+        dx = torch.empty((ctx.G * B, C), dtype=torch.float32, device=dout.device)
+        _lib.check(lib.facl_viewmax_bwd(_lib.ptr(dout), _lib.ptr(arg), ctx.G, B, C, _lib.ptr(dx), _lib.stream()), "facl_viewmax_bwd")
+        return dx, None
+
+
+def view_max(x_pre, G):
+    return _ViewMax.apply(x_pre, G)
+
+
 def linear(h, affine):
     return _Linear.apply(h, affine.weight, affine.bias)
 

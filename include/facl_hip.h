@@ -166,6 +166,11 @@ int facl_rows_segmax(const float* y, int64_t M, int S, int C, const float* bnc, 
                      void* stream);
 int facl_rows_bwd_stats(const float* dout, const float* y, int64_t R, int C, const float* bnc, double* sums,
                         void* ws, void* stream);
+/* gobaol_max_pool (cn3d_model_conbag.py:225-226) on the per-view maxima: x (G*B,C) view-major (row g*B+b) ->
+ * out (B,C) = max over the G views, arg (B,C) = first view that attains it; backward routes dout to that view's row
+ * of dx (G*B,C) and writes zeros elsewhere. */
+int facl_viewmax_fwd(const float* x, int G, int B, int C, float* out, int32_t* arg, void* stream);
+int facl_viewmax_bwd(const float* dout, const int32_t* arg, int G, int B, int C, float* dx, void* stream);
 /* dWc (C,3) fp64 = dy^T centers: the centroid-xyz columns of the first per-centroid layer's weight gradient
  * (the input of net3DV_3 is torch.cat((yt, xt), 1), cn3d_model_conbag.py:219) in one streaming pass over dy */
 int facl_rows_center_wgrad(const float* dy, const float* centers, int64_t R, int C, double* dWc, void* ws,

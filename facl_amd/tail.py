@@ -250,11 +250,26 @@ class _FCHead(torch.autograd.Function):
         segs = ((0, xa.shape[0]), (xa.shape[0], R))
         a = torch.empty_like(y)
         bncs, counts = [], []
-        for r0, r1 in segs:                                  # first the view rows, then the clip rows (:228, :229)
-            ys = y[r0:r1]
-            bnc, count = _forward_bn_consts(ys, bn, training, reduce_fn, ws)
-            _lib.check(lib.facl_rows_bn_relu(_lib.ptr(ys), r1 - r0, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a[r0:r1]),
-                                             _lib.stream()), "facl_rows_bn_relu")
+        if training:
+            # both segments' statistics first, ONE SyncBN all-reduce for the pair, then the two finalisations in the
+            # reference's order (view rows :228, clip rows :229: the running statistics are updated twice)
+            sums2 = torch.empty((2, C, 2), dtype=torch.float64, device=y.device)
+            for i, (r0, r1) in enumerate(segs):
+                _lib.check(lib.facl_rows_stats(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()),
+                           "facl_rows_stats")
+            world = 1
+            if reduce_fn is not None:
+                reduce_fn(sums2)
+                world = reduce_fn.world_size
+        for i, (r0, r1) in enumerate(segs):
+            if training:
+                count = float(r1 - r0) * world
+                bnc = _bn_finalize(sums2[i], C, count, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var)
+                bn.count_batch()
+            else:
+                bnc, count = _forward_bn_consts(y[r0:r1], bn, False, None, ws)
+            _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
+                                             _lib.ptr(a[r0:r1]), _lib.stream()), "facl_rows_bn_relu")
             bncs.append(bnc)
             counts.append(count)
         out, _ = gemm_fwd(a, W2, b2)
@@ -275,17 +290,19 @@ class _FCHead(torch.autograd.Function):
         db2 = dout.sum(0)
         dact = gemm_dgrad(dout, W2)
         dy = torch.empty_like(y)
-        dgamma = dbeta = None
-        for (r0, r1), bnc, count in zip(ctx.segs, (bnc_a, bnc_b), ctx.counts):
-            n = r1 - r0
-            sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
-            _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), n, C, _lib.ptr(bnc), _lib.ptr(sums),
-                                               _lib.ptr(ws), _lib.stream()), "facl_rows_bwd_stats")
-            dbe, dga, kk = _bn_bwd_consts(sums, C, count, ctx.reduce_fn)
-            _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), n, C, _lib.ptr(bnc), _lib.ptr(kk),
-                                               _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
-            dgamma = dga if dgamma is None else dgamma + dga
-            dbeta = dbe if dbeta is None else dbeta + dbe
+        f32 = dict(dtype=torch.float32, device=y.device)
+        sums2 = torch.empty((2, C, 2), dtype=torch.float64, device=y.device)
+        for i, ((r0, r1), bnc) in enumerate(zip(ctx.segs, (bnc_a, bnc_b))):
+            _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
+                                               _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()), "facl_rows_bwd_stats")
+        sums2_g = ctx.reduce_fn(sums2.clone()) if ctx.reduce_fn is not None else sums2       # one all-reduce for the pair
+        dbe, dga, kk = torch.empty((2, C), **f32), torch.empty((2, C), **f32), torch.empty((2, 2, C), **f32)
+        for i, ((r0, r1), bnc, count) in enumerate(zip(ctx.segs, (bnc_a, bnc_b), ctx.counts)):
+            _lib.check(lib.facl_bn_bwd_consts(_lib.ptr(sums2[i]), _lib.ptr(sums2_g[i]), C, float(count), _lib.ptr(dbe[i]),
+                                              _lib.ptr(dga[i]), _lib.ptr(kk[i]), _lib.stream()), "facl_bn_bwd_consts")
+            _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
+                                               _lib.ptr(kk[i]), _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
+        dgamma, dbeta = dga[0] + dga[1], dbe[0] + dbe[1]
         dW1 = gemm_wgrad(dy, h)
         dh = gemm_dgrad(dy, W1)
         na = ctx.segs[0][1]

@@ -11,6 +11,7 @@ namespace {
 
 constexpr int GROUP_THREADS = 256;           // 4 waves
 constexpr int CENTROIDS_PER_WG = 16;         // 4 per wave
+constexpr int CKEYS = 4;                     // keys per lane once the candidate set fits (radix select, second phase)
 
 // dist^2 exactly as the reference's fp32 chain: (dx*dx + dy*dy) + dz*dz, no FMA contraction.
 __device__ __forceinline__ float dist2_exact(float px, float py, float pz, float cx, float cy, float cz) {
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         // set shrinks to `remaining` after ~log2(N) mantissa bits, i.e. roughly half of the 31 rounds.
         uint32_t prefix = 0, hi = 0;
         int remaining = K, cand = NPL * 64;                     // padding keys (+inf) are ordinary candidates
-        for (int bit = 30; bit >= 0 && cand != remaining; --bit) {
+        int bit = 30;
+        for (; bit >= 0 && cand != remaining && cand > 64 * CKEYS; --bit) {
             hi = ~((2u << bit) - 1u);                           // bits above `bit`
             const uint32_t sel = hi | (1u << bit);
             int cnt = 0;
@@ -75,6 +77,39 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             if (total < remaining) { prefix |= (1u << bit); remaining -= total; cand -= total; }
             else cand = total;
             hi = sel;                                           // `bit` is resolved now
+        }
+        if (bit >= 0 && cand != remaining) {
+            // At most 64*CKEYS candidates are left (the range that holds the K-th smallest halves every round): gather
+            // them into CKEYS keys per lane through a small LDS slot and finish the remaining rounds -- typically half
+            // of them -- on those registers instead of walking all NPL.  Only prefix / hi / remaining come out of it;
+            // the emission below still uses the original registers, so no index bookkeeping is needed.
+            uint32_t* slot = reinterpret_cast<uint32_t*>(lds) + 4 * N + 64 * CKEYS * wave;
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const bool isc = (key[j] & hi) == prefix;
+                const unsigned long long m = __ballot(isc);
+                if (isc) slot[base + __popcll(m & lt)] = key[j];
+                base += __popcll(m);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+            uint32_t ck[CKEYS];
+            bool valid[CKEYS];
+#pragma unroll
+            for (int i = 0; i < CKEYS; ++i) {
+                valid[i] = lane + 64 * i < cand;
+                ck[i] = valid[i] ? slot[lane + 64 * i] : 0u;
+            }
+            for (; bit >= 0 && cand != remaining; --bit) {
+                const uint32_t sel = hi | (1u << bit);
+                int total = 0;
+#pragma unroll
+                for (int i = 0; i < CKEYS; ++i) total += __popcll(__ballot(valid[i] && (ck[i] & sel) == prefix));
+                if (total < remaining) { prefix |= (1u << bit); remaining -= total; cand -= total; }
+                else cand = total;
+                hi = sel;
+            }
+            asm volatile("" ::: "memory");                      // the slot is rewritten by the next centroid
         }
         // keys with (key & hi) < prefix are kept; of those equal to prefix under `hi`, the first `remaining`
         // in index order (all of them when the loop exited early; exact-tie rule otherwise)
@@ -115,7 +150,7 @@ template <int D, int NPL>
 int launch_group(const float* points, int M, int N, int S, int K, float r2, int32_t* idx, float* xt, float* yt,
                  hipStream_t st) {
     dim3 grid((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M);
-    const size_t lds = (size_t)N * 4 * sizeof(float);
+    const size_t lds = (size_t)N * 4 * sizeof(float) + 4 * 64 * CKEYS * sizeof(uint32_t);   // cloud (SoA) + one key slot per wave
     hipLaunchKernelGGL((k_group<D, NPL>), grid, dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt);
     return facl_launch_status();
 }

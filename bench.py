@@ -1,31 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- contrastive-step clips/sec on synthetic clouds (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]            # N > 1: starts its own N ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                 # ... or is started as one of them
 
 One "step" = one full training iteration of the reference loop body (cn3d_train_motion_GL.py:224-335) on a
 batch already resident in HBM: view-major reshape -> kNN/radius grouping -> encoder forward -> global + circle
 loss -> backward -> Adam.  Workload at N=1 = BASELINE.json configs[1]: motion stream, B=32, T=24 views,
-N=2048 points.  Weak scaling: every rank processes its own B=32 clips; the embeddings all-gather, SyncBN
-all-reduces and the gradient all-reduce are the exchange steps (facl_amd/dist.py).
-Prints ONE JSON line on rank 0.
+N=2048 points (`--config appearance` = configs[2], the appearance entry's step; `--config dense` = configs[4]).
+Weak scaling: every rank processes its own B clips; the embeddings all-gather, SyncBN all-reduces and the gradient
+all-reduce are the exchange steps (facl_amd/dist.py).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PEAK_MFMA_BF16_TFLOPS = 2500.0   # same guide, BF16 dense (the split-bf16 kernels run on this pipe)
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # same guide, BF16/FP16 dense (the split-bf16 and the fp16 kernels run on this pipe)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -34,15 +33,56 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--B", type=int, default=32, help="clips per GPU")
-    ap.add_argument("--T", type=int, default=24, help="views per clip (reference: gost / num_crop)")
-    ap.add_argument("--N", type=int, default=2048)
+    ap.add_argument("--config", choices=("motion", "appearance", "dense"), default="motion",
+                    help="motion = BASELINE configs[1] (headline); appearance = configs[2]; dense = configs[4]")
+    ap.add_argument("--B", type=int, default=None, help="clips per GPU (default 32; dense: 8)")
+    ap.add_argument("--T", type=int, default=None, help="views per clip (reference: gost / num_crop; default 24, dense 32)")
+    ap.add_argument("--N", type=int, default=None, help="points per view (default 2048, dense 4096)")
     ap.add_argument("--D", type=int, default=3, help="input channels (north_star: 3-ch; checkpoints: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fps", type=int, default=0, help="1: FPS-reorder the views on the GPU inside the timed step")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (single GPU only)")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    dflt = {"motion": (32, 24, 2048), "appearance": (32, 24, 2048), "dense": (8, 32, 4096)}[a.config]
+    a.B = dflt[0] if a.B is None else a.B
+    a.T = dflt[1] if a.T is None else a.T
+    a.N = dflt[2] if a.N is None else a.N
+    return a
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without an outer launcher: become the launcher.  Nothing in this branch touches the GPU (device_count() does not
+# initialise HIP on this image); the ranks are fresh child processes and this process only relays their JSON line.
+def spawn_ranks(a):
+    import torch
+    have = torch.cuda.device_count()
+    rehearsal = os.environ.get("FACL_DIST_BACKEND") == "gloo"          # N ranks on fewer devices: CPU-collective rehearsal only
+    if have < a.gpus and not rehearsal:
+        print("bench.py: --gpus %d requested but only %d device(s) visible" % (a.gpus, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.lstrip().startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0 or line is None:
+        print("bench.py: the %d-rank child run failed (exit %d)" % (a.gpus, rc), file=sys.stderr)
+        return rc or 1
+    print(line)
+    return 0
 
 
 def make_opt(a):
@@ -61,66 +101,128 @@ def _baseline_metric():
 
 
 def _pmc_traffic(a, kernel):
-    # HBM bytes per launch: PMC counters are collected offline (rocprofv3 --pmc, profiles/pmc_traffic.json) at this
-    # exact shape; reported only when the shape matches, else null.
+    """HBM bytes per launch from OFFLINE PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/pmc_traffic.json):
+    reported only when the shape matches the one the counters were collected at, else null.  (label, build) tell
+    which build the counters belong to."""
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if pm["shape"] == {"B": a.B, "T": a.T, "N": a.N, "D": a.D}:
-            return pm.get(kernel)
+            return pm.get(kernel), "offline rocprofv3 --pmc, build %s" % pm.get("build", "r01")
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def dominant_kernel_roofline(a, eager_step, batches, nsteps=8):
-    """Average duration of the three heaviest kernels measured INSIDE the training step: `nsteps` extra eager steps
-    (after the timed region) with HIP events recorded on the launch stream around the three launches
-    (facl_amd/_lib.py: timed).  `roofline` is the single longest kernel, k_sa_bwd1 (HBM-side: it streams y2 in and dz2
-    out, its MFMA part is small); `roofline_more` carries the two MFMA kernels (k_sa_fwd3_sb and the largest
-    k_gemm_sb), priced against the bf16 MFMA peak with the bf16 FLOPs they EXECUTE (6 per fp32 multiply-add, see
-    DESIGN.md).  The brackets include the two ~5 us partial-sum reduction launches that follow each of these kernels
-    inside its C entry point."""
+# ---------------------------------------------------------------------------------------------------------------------
+# Roofline models of the heavy entry points (DESIGN.md section 3 derives every figure).  A "unit" is one group of 64
+# neighbour positions; nunits = M*S.  pipe "f32": v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s, algorithmic FLOPs);
+# pipe "bf16x6": exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16 -- 6 executed bf16 FLOPs per algorithmic one, priced
+# against the 2.5 PFLOP/s dense bf16 peak.
+def kernel_models(a, S=64, K=64):
+    M = a.B * a.T
+    nunits, D = M * S, a.D
+    sa_f32 = os.environ.get("FACL_SA_F32") == "1"
+    y2 = 64 * 64 * 4                                   # one (64 pos x 64 ch) fp32 tile
+    return {
+        "facl_group": dict(kernel="k_group", flops=M * S * a.N * 8.0, pipe="valu",
+                           bytes=M * (a.N * D * 4.0 + S * K * D * 4.0 + S * 12.0)),
+        "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "bf16x6",
+                             flops=nunits * 2.0 * 64 * 64 * 64, bytes=nunits * (64 * D * 4.0 + y2)),
+        "facl_sa_fwd3": dict(kernel="k_sa_fwd3" if sa_f32 else "k_sa_fwd3_sb", pipe="f32" if sa_f32 else "bf16x6",
+                             flops=nunits * 2.0 * 64 * 64 * 256, bytes=nunits * (y2 + 1024.0 + 256.0)),
+        "facl_sa_bwd1": dict(kernel="k_sa_bwd1", pipe="f32", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
+                             bytes=nunits * (2.0 * y2 + 1024 + 256)),
+        "facl_sa_bwd_w3": dict(kernel="k_sa_bwd_w3", pipe="f32", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
+                               bytes=nunits * (y2 + 1024.0 + 256.0)),
+        # da1 = dy2 W2 (2*64*64) + dW2 += dy2^T a1 (2*64*64) + R1 += [x|1]^T dz1 (2*64*4) per position
+        "facl_sa_bwd2": dict(kernel="k_sa_bwd2", pipe=os.environ.get("FACL_BWD2_PIPE", "f32"),
+                             flops=nunits * 64.0 * (2 * 64 * 64 + 2 * 64 * 64 + 2 * 64 * 4),
+                             bytes=nunits * (2.0 * y2 + 64 * D * 4.0)),
+    }
+
+
+def _gemm_model(label):
+    kind, dims = label.split()
+    m, k, n = (int(v) for v in dims.split("x"))
+    pipe = "f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6"
+    name = {"facl_gemm_fwd": "k_gemm_sb fwd", "facl_gemm_dgrad": "k_gemm_sb dgrad", "facl_gemm_wgrad": "k_gemm_sb wgrad"}[kind]
+    return dict(kernel="%s %s" % (name, dims), pipe=pipe, flops=2.0 * m * k * n, bytes=4.0 * (m * k + k * n + m * n))
+
+
+def price(model, ms):
+    """One roofline record: both roofs are evaluated, `bound` is the one that allows the LONGER time at its peak."""
+    sec = ms * 1e-3
+    ex = model["flops"] * (6.0 if model["pipe"] == "bf16x6" else 1.0)
+    peak_tf = PEAK_MFMA_BF16_TFLOPS if model["pipe"] in ("bf16x6", "f16") else PEAK_MFMA_F32_TFLOPS
+    t_mfma = ex / (peak_tf * 1e12) if model["pipe"] != "valu" else 0.0
+    t_hbm = model["bytes"] / (PEAK_HBM_GBPS * 1e9)
+    rec = {"kernel": model["kernel"], "ms_per_launch": round(ms, 4)}
+    if t_mfma >= t_hbm:
+        ach = ex / sec / 1e12
+        rec.update(bound="mfma", achieved=round(ach, 1), peak=peak_tf, unit="TFLOP/s", frac=round(ach / peak_tf, 4))
+    else:
+        ach = model["bytes"] / sec / 1e9
+        rec.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(ach / PEAK_HBM_GBPS, 4))
+    rec.update(pipe=model["pipe"], algorithmic_flops_per_launch=model["flops"], algorithmic_bytes_per_launch=model["bytes"],
+               algorithmic_tflops=round(model["flops"] / sec / 1e12, 1), hbm_frac=round(model["bytes"] / sec / 1e9 / PEAK_HBM_GBPS, 4))
+    if model["pipe"] == "bf16x6":
+        rec["executed_bf16_flops_per_launch"] = ex
+    return rec
+
+
+def step_rooflines(a, eager_step, batches, nsteps=8):
+    """Every heavy entry point of the step timed INSIDE the training step: `nsteps` extra eager steps (after the timed
+    region) with HIP events recorded on the launch stream around each entry (facl_amd/_lib.py: timed; a stand-alone
+    loop of one kernel sits elsewhere on the clock/power curve and would not match the rocprof average of the real
+    run).  The brackets include the one or two ~5 us partial-sum reduction launches an entry issues after its kernel.
+    Returns (roofline of the LONGEST kernel, the others sorted by time)."""
     from facl_amd import _lib
-    nunits = a.B * a.T * 64
-    M, K, N = nunits, 512, 1024
-    glabel = "facl_gemm_fwd %dx%dx%d" % (M, K, N)
-    _lib.TIMING = {"facl_sa_bwd1": [], "facl_sa_fwd3": [], glabel: []}
+    _lib.TIMING = {}
     try:
         for i in range(nsteps):
             eager_step(batches[i % 2], epoch=0)
-        ms1, ms3, msg = _lib.timing_ms("facl_sa_bwd1"), _lib.timing_ms("facl_sa_fwd3"), _lib.timing_ms(glabel)
+        table = _lib.timing_table()
     finally:
         _lib.TIMING = None
-    # ---- k_sa_bwd1: y2 (16 KiB/unit) + coef (1 KiB) + arg (256 B) in, dz2 (16 KiB) out
-    bytes1 = float(nunits) * (2 * 16384 + 1024 + 256)
-    ach1 = bytes1 / (ms1 * 1e-3) / 1e9
-    main = {"kernel": "k_sa_bwd1", "bound": "hbm", "achieved": round(ach1, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-            "frac": round(ach1 / PEAK_HBM_GBPS, 4), "traffic": _pmc_traffic(a, "k_sa_bwd1"),
-            "ms_per_launch": round(ms1, 4), "algorithmic_bytes_per_launch": bytes1, "measured": "in-step, %d steps" % nsteps}
-    # ---- k_sa_fwd3_sb: 64 -> 256 layer of the SA-MLP, 2*64*256 FLOP per position (SURVEY 8d), x6 bf16 MFMA FLOPs
-    fl3 = 2.0 * 64 * 256 * nunits * 64
-    more = [{"kernel": "k_sa_fwd3_sb", "bound": "mfma", "achieved": round(6 * fl3 / (ms3 * 1e-3) / 1e12, 1),
-             "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(6 * fl3 / (ms3 * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4),
-             "traffic": _pmc_traffic(a, "k_sa_fwd3_sb"), "ms_per_launch": round(ms3, 4), "algorithmic_flops_per_launch": fl3,
-             "algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * fl3}]
-    # ---- largest tail GEMM (net3DV_3.6: 512 -> 1024 over the M*S centroid rows), forward
-    if msg is not None:
-        flg = 2.0 * M * K * N
-        more.append({"kernel": "k_gemm_sb<KC,KC> %dx%dx%d (+ fused max over the 64 centroids)" % (M, K, N), "bound": "mfma",
-                     "achieved": round(6 * flg / (msg * 1e-3) / 1e12, 1), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(6 * flg / (msg * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
-                     "ms_per_launch": round(msg, 4), "algorithmic_flops_per_launch": flg,
-                     "algorithmic_tflops": round(flg / (msg * 1e-3) / 1e12, 1), "executed_bf16_flops_per_launch": 6 * flg})
-    return main, more
+    models = kernel_models(a)
+    recs = []
+    for label, (ms, n) in table.items():
+        m = models.get(label) or (_gemm_model(label) if label.startswith("facl_gemm_") else None)
+        if m is None or ms < 0.02:                       # sub-20-us launches are glue, not roofline material
+            continue
+        r = price(m, ms)
+        r["launches_per_step"] = round(n / nsteps, 2)
+        r["measured"] = "in-step HIP events, %d eager steps" % nsteps
+        r["traffic"], src = _pmc_traffic(a, m["kernel"])
+        if src:
+            r["traffic_source"] = src
+        recs.append(r)
+    recs.sort(key=lambda r: -r["ms_per_launch"])
+    return recs[0], recs[1:]
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(a):
-    """The oracle's training step (a port of the reference's op sequence onto torch-CPU) timed on the host
-    cores, on a bounded sample: `cpu_clips` clips of the same (T, N, D) shape."""
+    """The oracle's training step (a port of the reference's op sequence onto torch-CPU; timed against the imported
+    reference in the build container: x1.04-1.08) on the host cores, on a bounded sample:
+    `cpu_clips` clips of the same (T, N, D) shape, 1 warm-up + 3 timed steps."""
+    import numpy as np
+    import torch
     from oracle import step as OS
     from oracle import encoder as E
     from oracle.weights import formula_state_dict
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     Bc, G = a.cpu_clips, a.T
     sd = E.clone_state(formula_state_dict(a.D))
@@ -128,48 +230,70 @@ def cpu_baseline(a):
     g = torch.Generator().manual_seed(0)
     order = np.arange(G)
     times = []
-    for it in range(3):
+    for it in range(4):
         pts = OS.view_major(torch.rand(Bc, G, a.N, a.D, generator=g) - 0.5)
         t0 = time.time()
         OS.train_step(sd, opt, pts, Bc, G, 64, 64, 0.16 if a.N != 512 else 0.06, order)
         times.append(time.time() - t0)
-    t = min(times[1:])
+    t = float(np.median(times[1:]))
     return {"value": round(Bc / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"B={Bc} clips x T={G} views x N={a.N} pts, D={a.D}: 1 warm-up + 2 timed steps "
-                      f"(best {t:.2f} s/step) of oracle.step.train_step"}
+            "sample": f"B={Bc} clips x T={G} views x N={a.N} pts, D={a.D}: 1 warm-up + 3 timed steps "
+                      f"(median {t:.2f} s/step, first {times[0]:.2f} s) of oracle.step.train_step"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    import numpy as np
+    import torch
     from facl_amd import dist as fdist
     rank, world = fdist.init_from_env()
-    # one rank per GPU; `% device_count` only matters when rehearsing N>1 on a single-GPU box
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    if world != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("FACL_DIST_BACKEND") != "gloo":
+        print("bench.py: %d ranks but only %d device(s) visible" % (world, ndev), file=sys.stderr)
+        sys.exit(2)
+    # one rank per GPU; `% device_count` only matters for the gloo rehearsal of N>1 on a single-GPU box
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    from facl_amd.cn3d_model_conbag import PointNet_Plus
-    from facl_amd.train_common import ContrastiveStep, GraphedStep, synthetic_batch
 
     torch.manual_seed(1)                       # opt.manualSeed = 1 (cn3d_train_motion_GL.py:142-144)
     np.random.seed(1)
-    opt = make_opt(a)
-    net = PointNet_Plus(opt, gost=a.T).to(dev).train()
-    net.bn_reduce_fn = fdist.make_bn_reduce_fn()
-    use_graph = bool(a.graph) and world == 1
-    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, capturable=use_graph, fused=True)
-    step = ContrastiveStep(net, optim, opt, a.T, fps_reorder=bool(a.fps))
-    eager_step = step
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(rank)
-    batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]   # resident in HBM
-    mode = "eager"
-    if use_graph:
-        try:
-            step = GraphedStep(step, batches[0], a.T)
-            mode = "hipgraph"
-        except Exception as e:                          # never lose the measurement to a capture problem
-            print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
-            net.zero_grad(set_to_none=True)
+    if a.config == "dense":
+        from facl_amd import dense as fdense
+        step, eager_step, batches, mode, workload, dtype, dtype_note = fdense.make_bench_step(a, dev, rank, world)
+    else:
+        from facl_amd.cn3d_model_conbag import PointNet_Plus
+        from facl_amd.train_common import ContrastiveStep, GraphedStep, synthetic_batch, appearance_batch
+        opt = make_opt(a)
+        net = PointNet_Plus(opt, gost=a.T).to(dev).train()
+        net.bn_reduce_fn = fdist.make_bn_reduce_fn()
+        use_graph = bool(a.graph) and world == 1
+        optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, capturable=use_graph, fused=True)
+        step = ContrastiveStep(net, optim, opt, a.T, fps_reorder=bool(a.fps))
+        eager_step = step
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(rank)
+        make = appearance_batch if a.config == "appearance" else synthetic_batch
+        batches = [make(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]   # resident in HBM
+        mode = "eager"
+        if use_graph:
+            try:
+                step = GraphedStep(step, batches[0], a.T)
+                mode = "hipgraph"
+            except Exception as e:                          # never lose the measurement to a capture problem
+                print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+                net.zero_grad(set_to_none=True)
+        stream = "motion" if a.config == "motion" else "appearance"
+        workload = (f"{stream} stream, B={a.B}/GPU T={a.T} N={a.N} D={a.D}, S=64 K=64, full cn3d_model_conbag encoder, "
+                    f"global+circle loss, backward, Adam")
+        dtype = "f32"
+        dtype_note = ("fp32 storage and accumulation; dense contractions as exact 3-way bf16 splits on the bf16 MFMA "
+                      "(6 products per multiply-add, fp32-grade accuracy)")
 
     def barrier():
         if world > 1:
@@ -191,20 +315,18 @@ def main():
     final_loss = float(loss.item())
 
     # in-step kernel timing: extra eager steps on EVERY rank (they contain the collectives), reported by rank 0
-    rl_main, rl_more = dominant_kernel_roofline(a, eager_step, batches)
+    rl_main, rl_more = step_rooflines(a, eager_step, batches)
     out = None
     if rank == 0:
         clips = a.B * world * a.steps / dt
         out = {"metric": _baseline_metric(), "value": round(clips, 2), "unit": "clips/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "dtype_note": "fp32 storage and accumulation; dense contractions as exact 3-way bf16 splits on the bf16 MFMA (6 products per multiply-add, fp32-grade accuracy)",
-               "config": {"workload": f"motion stream, B={a.B}/GPU T={a.T} N={a.N} D={a.D}, S=64 K=64, full "
-                                      f"cn3d_model_conbag encoder, global+circle loss, backward, Adam",
-                          "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode},
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "dtype_note": dtype_note,
+               "config": {"workload": workload, "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode},
                "final_loss": final_loss}
         out["roofline"], out["roofline_more"] = rl_main, rl_more
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.config != "dense":
             out["cpu_baseline"] = cpu_baseline(a)
     if world > 1:
         torch.distributed.barrier()

@@ -114,14 +114,15 @@ def require_cuda(*tensors):
 
 
 # ---- optional in-step kernel timing (bench.py's roofline section) ----------------------------------------------------
-# When TIMING is a dict {label: []}, `timed(label)` brackets the launches issued inside the `with` block with HIP
-# events on the launch stream (eager execution only: events cannot be recorded inside a graph replay).
+# When TIMING is a dict, `timed(label)` brackets the launches issued inside the `with` block with HIP events on the
+# launch stream (eager execution only: events cannot be recorded inside a graph replay) and appends the event pair to
+# TIMING[label] (created on first use, so bench.py sees every heavy entry point of the step without a fixed list).
 TIMING = None
 
 
 class timed:
     def __init__(self, label):
-        self.on = TIMING is not None and label in TIMING
+        self.on = TIMING is not None
         self.label = label
 
     def __enter__(self):
@@ -135,14 +136,21 @@ class timed:
         if self.on:
             import torch
             self.e1.record(torch.cuda.current_stream())
-            TIMING[self.label].append((self.e0, self.e1))
+            TIMING.setdefault(self.label, []).append((self.e0, self.e1))
         return False
 
 
 def timing_ms(label):
     """Average milliseconds of the recorded brackets of `label` (synchronises)."""
-    evs = TIMING[label]
+    evs = TIMING.get(label)
     if not evs:
         return None
     evs[-1][1].synchronize()
     return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+
+
+def timing_table():
+    """{label: (average ms per bracket, number of brackets)} for everything recorded so far (synchronises)."""
+    import torch
+    torch.cuda.synchronize()
+    return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in TIMING.items() if v}

@@ -44,37 +44,47 @@ def make_bn_reduce_fn(group=None):
     return reduce_fn
 
 
+def _use_reduce_scatter(group=None):
+    """Decided ONCE per process group, before any collective is issued: the backward of the embeddings all-gather is a
+    reduce-scatter on RCCL (each rank needs only the sum of ITS rows: 1/R of the all-reduce traffic) and an all-reduce
+    + slice on gloo (the CPU rehearsal backend has no reduce_scatter_tensor).  Every rank evaluates the same
+    expression on the same backend, so the ranks cannot diverge; a failing collective raises and the rank exits."""
+    key = id(group)
+    if key not in _RS_DECISION:
+        _RS_DECISION[key] = dist.get_backend(group) == "nccl" and hasattr(dist, "reduce_scatter_tensor")
+    return _RS_DECISION[key]
+
+
+_RS_DECISION = {}
+
+
 class _AllGatherViewMajor(torch.autograd.Function):
     """(G*B_l, C) view-major local rows -> (G*R*B_l, C) view-major global rows (row = g*(R*B_l) + r*B_l + b).
 
-    Forward semantics follow ``concat_all_gather`` (gather list -> cat), plus the re-layout that the
-    view-major row order needs (SURVEY hard part 5).  Backward = sum over ranks of the gathered gradient,
-    sliced back to the local rows (the single-process loss back-propagates through the negatives)."""
+    Forward semantics follow ``concat_all_gather`` (cn3d_model_conbag.py:559-570: gather -> cat on dim 0), plus the
+    re-layout that the view-major row order needs (SURVEY hard part 5): ONE all_gather_into_tensor into a rank-major
+    (R,G,B_l,C) buffer, then one permuted copy.  Backward = sum over ranks of the gathered gradient restricted to the
+    local rows (the single-process loss back-propagates through the negatives)."""
 
     @staticmethod
     def forward(ctx, x, G, group):
         R = dist.get_world_size(group)
         r = dist.get_rank(group)
-        xs = [torch.empty_like(x) for _ in range(R)]
-        dist.all_gather(xs, x.contiguous(), group=group)
         Bl, C = x.shape[0] // G, x.shape[1]
-        full = torch.stack([t.view(G, Bl, C) for t in xs], dim=1)           # (G,R,Bl,C)
+        buf = torch.empty((R * G * Bl, C), dtype=x.dtype, device=x.device)      # concatenation along dim 0: rank-major
+        dist.all_gather_into_tensor(buf, x.contiguous(), group=group)
         ctx.meta = (G, R, r, Bl, C, group)
-        return full.reshape(G * R * Bl, C)
+        return buf.view(R, G, Bl, C).permute(1, 0, 2, 3).reshape(G * R * Bl, C)  # (G,R,Bl,C) view-major rows
 
     @staticmethod
     def backward(ctx, g):
         G, R, r, Bl, C, group = ctx.meta
-        if dist.get_backend(group) == "nccl":
-            # reduce-scatter: each rank only needs the sum of ITS rows (1/R of the all-reduce traffic)
-            try:
-                gin = g.view(G, R, Bl, C).permute(1, 0, 2, 3).contiguous()      # (R, G, Bl, C): rank-major chunks
-                out = torch.empty((G, Bl, C), dtype=g.dtype, device=g.device)
-                dist.reduce_scatter_tensor(out, gin, op=dist.ReduceOp.SUM, group=group)
-                return out.reshape(G * Bl, C), None, None
-            except (RuntimeError, AttributeError, ValueError):                  # argument validation: same on every rank
-                pass
-        g = g.contiguous()                                                    # gloo (CPU rehearsal): no reduce-scatter
+        if _use_reduce_scatter(group):
+            gin = g.view(G, R, Bl, C).permute(1, 0, 2, 3).contiguous()          # (R,G,Bl,C): rank-major chunks
+            out = torch.empty((G * Bl, C), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(out, gin.view(R * G * Bl, C), op=dist.ReduceOp.SUM, group=group)
+            return out, None, None
+        g = g.contiguous()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
         return g.view(G, R, Bl, C)[:, r].reshape(G * Bl, C), None, None
 

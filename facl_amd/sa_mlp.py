@@ -128,8 +128,9 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
                                  _lib.ptr(l1tab), st), "facl_sa_l1tab")
     y2f = torch.empty(nunits * UNIT * 64, dtype=torch.float32, device=dev)
     sums2 = torch.empty((64, 2), **f64) if training else None
-    _lib.check(lib.facl_sa_fwd2(_lib.ptr(x_rows), nunits, D, _lib.ptr(l1tab), _lib.ptr(W2), _lib.ptr(p["b2"]),
-                                _lib.ptr(y2f), _lib.ptr(sums2), _lib.ptr(ws), st), "facl_sa_fwd2")
+    with _lib.timed("facl_sa_fwd2"):
+        _lib.check(lib.facl_sa_fwd2(_lib.ptr(x_rows), nunits, D, _lib.ptr(l1tab), _lib.ptr(W2), _lib.ptr(p["b2"]),
+                                    _lib.ptr(y2f), _lib.ptr(sums2), _lib.ptr(ws), st), "facl_sa_fwd2")
     if training:
         if reduce_fn is not None:
             reduce_fn(sums2)
@@ -223,15 +224,17 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
 
     # ---- layer-3 weight gradient ingredients: sparse gather, Gram, sum a2
     out3 = torch.empty(256 * 64 + 64 * 64 + 64, **f64)
-    _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
-               "facl_sa_bwd_w3")
+    with _lib.timed("facl_sa_bwd_w3"):
+        _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
+                   "facl_sa_bwd_w3")
 
     # ---- pass 2: dy2, da1, dz1, dW2, R1
     bw2 = torch.empty((4, 64), **f32)
     _lib.check(lib.facl_sa_bwd_consts2(ptr(sums1), ptr(bnc2), P, ptr(bw2), st), "facl_sa_bwd_consts2")
     out2 = torch.empty(64 * 64 + 8 * 64, **f64)
-    _lib.check(lib.facl_sa_bwd2(ptr(dz2f), ptr(ctx["y2f"]), ptr(x_rows), nunits, D, ptr(bw2), ptr(W2), ptr(ctx["l1tab"]),
-                                ptr(out2), ptr(ws), st), "facl_sa_bwd2")
+    with _lib.timed("facl_sa_bwd2"):
+        _lib.check(lib.facl_sa_bwd2(ptr(dz2f), ptr(ctx["y2f"]), ptr(x_rows), nunits, D, ptr(bw2), ptr(W2), ptr(ctx["l1tab"]),
+                                    ptr(out2), ptr(ws), st), "facl_sa_bwd2")
     R1_g = out2[4096:]
     if reduce_fn is not None:
         R1_g = reduce_fn(R1_g.clone())

@@ -33,8 +33,9 @@ def gemm_dgrad(dy, W):
     M, N = dy.shape
     K = W.shape[1]
     da = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-    _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
-               "facl_gemm_dgrad")
+    with _lib.timed("facl_gemm_dgrad %dx%dx%d" % (M, N, K)):
+        _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
+                   "facl_gemm_dgrad")
     return da
 
 
@@ -47,8 +48,9 @@ def gemm_wgrad(dy, a):
     nz = max(1, min((M + 255) // 256, 512 // tiles))     # tiles * nz = one resident wave of workgroups (2 per CU)
     dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = torch.empty(nz * N * K, dtype=torch.float32, device=dy.device)
-    _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
-                                   _lib.stream()), "facl_gemm_wgrad")
+    with _lib.timed("facl_gemm_wgrad %dx%dx%d" % (M, N, K)):
+        _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
+                                       _lib.stream()), "facl_gemm_wgrad")
     return dW
 
 

@@ -70,6 +70,34 @@ def synthetic_batch(B, G, N, D, device, generator=None):
     return torch.rand(B, G, N, D, device=device, generator=generator) - 0.5
 
 
+def appearance_batch(B, G, N, D, device, generator=None):
+    """(B,G,N,D) float32 appearance-style synthetic clips (BASELINE configs[2]; SURVEY hard part 7).
+
+    What the appearance branch feeds the same model (cn3D_data_set.py:125-137, generate_NTU.py:249-264): per clip ONE
+    voxelised body surface -- 30 mm voxels normalised by the body height, i.e. coordinates on a ~1/64 grid with y in
+    [-0.5,0.5], a narrower x and a thin depth relief, 4th channel an appearance value in [-0.5,0.5] -- and every view
+    = N rows drawn WITH replacement from it (get_data_train, :287-318), so clouds contain duplicated rows (exact
+    distance ties in the kNN) and grid-aligned neighbours.  Views g >= 1 are jittered (sigma 0.01, clip 0.05, :767-778),
+    odd views x-mirrored (:708-713); view 0 is the raw resample and keeps its exact duplicates."""
+    P0 = max(64, int(0.6 * N))
+    r = lambda *shape: torch.rand(*shape, device=device, generator=generator)
+    bx = (r(B, P0) - 0.5) * 0.44
+    by = r(B, P0) - 0.5
+    bz = 0.08 * torch.sin(6.0 * bx) * torch.cos(4.0 * by) + (r(B, P0) - 0.5) * 0.04
+    base = torch.stack((bx, by, bz), dim=-1)
+    base = torch.round(base * 64.0) / 64.0                                     # voxel grid
+    if D == 4:
+        app = torch.round((r(B, P0, 1) - 0.5) * 16.0) / 16.0
+        base = torch.cat((base, app), dim=-1)
+    idx = torch.randint(0, P0, (B, G, N), device=device, generator=generator)
+    out = torch.gather(base.unsqueeze(1).expand(B, G, P0, D), 2, idx.unsqueeze(-1).expand(B, G, N, D)).clone()
+    if G > 1:
+        noise = (0.01 * torch.randn(B, G - 1, N, 3, device=device, generator=generator)).clamp_(-0.05, 0.05)
+        out[:, 1:, :, :3] += noise
+        out[:, 1::2, :, 0] *= -1.0
+    return out.float()
+
+
 class ContrastiveStep:
     """One training iteration = the loop body of cn3d_train_motion_GL.py:224-335."""
 
@@ -139,9 +167,15 @@ class GraphedStep:
                 step.run(self.points, self.order)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # The capture pass runs the Python forward (no kernel executes), so the host-side num_batches_tracked counters
+        # would run ahead of the running-statistics updates: restore them afterwards.  NOTE: the 3 warm-up calls above
+        # are REAL optimizer steps on `example_points` (they also settle the allocator and Adam's lazy state).
+        saved = [(m, m.steps) for m in self._bn_modules()]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = step.run(self.points, self.order)
+        for m, n in saved:
+            m.steps = n
 
     def _bn_modules(self):
         return [m for m in self.step.netR.modules() if hasattr(m, "count_batch")]

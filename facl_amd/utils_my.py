@@ -24,8 +24,9 @@ def knn_radius_group(points, sample_num_level1, knn_K, ball_radius, want_idx=Fal
     yt = torch.empty((M, S, 3), dtype=torch.float32, device=pts.device)
     idx = torch.empty((M, S, K), dtype=torch.int32, device=pts.device) if want_idx else None
     lib = _lib.load_library()
-    _lib.check(lib.facl_group(_lib.ptr(pts), M, N, D, S, K, float(ball_radius), _lib.ptr(idx), _lib.ptr(xt),
-                              _lib.ptr(yt), _lib.stream()), "facl_group")
+    with _lib.timed("facl_group"):
+        _lib.check(lib.facl_group(_lib.ptr(pts), M, N, D, S, K, float(ball_radius), _lib.ptr(idx), _lib.ptr(xt),
+                                  _lib.ptr(yt), _lib.stream()), "facl_group")
     inputs_level1 = xt.permute(0, 3, 1, 2)                       # (M,D,S,K), utils_my.py:283
     inputs_level1_center = yt.view(M, 1, S, 3).transpose(1, 3)   # (M,3,S,1), utils_my.py:284
     if want_idx:

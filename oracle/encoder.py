@@ -23,7 +23,7 @@ def _conv_bn_relu(sd, prefix, li, x, training):
                      training, BN_MOMENTUM, BN_EPS)
     if training:
         sd[f"{prefix}.{b}.num_batches_tracked"] += 1
-    return F.relu(x)
+    return F.relu(x, inplace=True)                                    # nn.ReLU(inplace=True), :47
 
 
 def _fc_head(sd, x, training):
@@ -33,7 +33,7 @@ def _fc_head(sd, x, training):
                      sd["netR_FC.1.weight"], sd["netR_FC.1.bias"], training, BN_MOMENTUM, BN_EPS)
     if training:
         sd["netR_FC.1.num_batches_tracked"] += 1
-    x = F.relu(x)
+    x = F.relu(x, inplace=True)                                       # :204
     return F.linear(x, sd["netR_FC.3.weight"], sd["netR_FC.3.bias"])
 
 

@@ -224,11 +224,70 @@ def make_init():
     print("init.npz", len(out))
 
 
+def make_level2():
+    """Second-level groupers on channel-first features (utils_my.py:332-356 group_points_2: K = 64 literal, radius =
+    the tensor argument; :358-381 group_points_2_3DV: K = 32 and r^2 = 0.11 literals).  No model of the reference
+    consumes them; they are the only reference text the multi-level (dense, BASELINE configs[4]) set abstraction can
+    follow, so the level-2 grouping kernel and its oracle restatement are pinned here."""
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    B, C, S1, S2 = 3, 5, 128, 32
+    pts = torch.rand(B, 3 + C, S1, generator=g) - 0.5
+    out["points"] = pts.numpy().copy()
+    out["meta"] = np.array([B, C, S1, S2], dtype=np.int32)
+    for tag, r in (("r005", 0.05), ("r030", 0.30)):
+        xt, ct = R_utils.group_points_2(pts.clone(), S1, S2, 64, torch.tensor(r))
+        out[f"gp2_{tag}"] = canon_groups(xt)                                   # (B,S2,64,3+C), K axis sorted
+        out[f"gp2_{tag}_center"] = ct.contiguous().numpy()
+    xt, ct = R_utils.group_points_2_3DV(pts.clone(), S1, S2, 0, None)
+    out["gp2_3dv"] = canon_groups(xt)                                          # (B,S2,32,3+C)
+    out["gp2_3dv_center"] = ct.contiguous().numpy()
+    # the input must not be modified by the in-place centring (the gather makes a copy)
+    assert np.array_equal(pts.numpy(), out["points"])
+    np.savez_compressed(os.path.join(OUT, "level2.npz"), **out)
+    print("level2.npz", {k: v.shape for k, v in out.items()})
+
+
+def make_fc():
+    """linear_classify/fc_model.py:12-25 Final_FC: seeded construction (fingerprints of the N(0, 0.01) weights),
+    forward on synthetic features, CrossEntropy loss and its gradients."""
+    sys.path.insert(0, "/root/reference/linear_classify")
+    import fc_model as R_fc                                                     # reference
+    out = {}
+    torch.manual_seed(3)
+    net = R_fc.Final_FC()
+    w = net.fc.weight.detach().numpy().astype(np.float64).reshape(-1)
+    out["init_fingerprint"] = np.concatenate(([w.size, w.sum(), np.abs(w).sum()], w[:8]))
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(6, 22 * 512, generator=g) * 3.0 + 0.5
+    y = torch.tensor([5, 0, 119, 7, 7, 64])
+    wf = torch.as_tensor(_wave_fc(120 * 22 * 512)).view(120, 22 * 512)
+    bf = torch.as_tensor(_wave_fc(120, key=1))
+    with torch.no_grad():
+        net.fc.weight.copy_(wf)
+        net.fc.bias.copy_(bf)
+    pred = net(x)
+    loss = torch.nn.CrossEntropyLoss()(pred, y)
+    loss.backward()
+    out.update(x=x.numpy(), y=y.numpy(), pred=pred.detach().numpy(), loss=np.float64(loss.item()),
+               grad_bias=net.fc.bias.grad.numpy().copy(), gradnorm_weight=np.float64(net.fc.weight.grad.double().norm().item()),
+               gradhead_weight=net.fc.weight.grad.reshape(-1)[:4096].numpy().copy())
+    np.savez_compressed(os.path.join(OUT, "fc.npz"), **out)
+    print("fc.npz", {k: np.shape(v) for k, v in out.items()})
+
+
+def _wave_fc(n, key=0):
+    from oracle.weights import _hash_uniform
+    return (0.02 * _hash_uniform(n, 555 + key)).astype(np.float32)
+
+
 def main():
     argparse.ArgumentParser(description=__doc__).parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     make_init()
+    make_level2()
+    make_fc()
     make_fps()
     make_tiny()
     run_c1(4, False, "d4")

@@ -35,17 +35,43 @@ def farthest_point_sampling_fast(pc, sample_num, start_idx=None):
     return farthest_point_sampling_batch(pc.unsqueeze(0), sample_num, [start_idx]).view(sample_num, 1)
 
 
-def fps_sample_data(points_xyzc, sample_num_level1, start_idx=None):
-    """Reorder every cloud so its FPS picks come first (cn3D_data_set.py:665-672).
-    points (b,N,D) float32 CUDA -> new tensor (the reference permutes in place)."""
+def _reorder(pts, picks, m):
+    out = torch.empty_like(pts)
+    b, N, D = pts.shape
+    lib = _lib.load_library()
+    _lib.check(lib.facl_fps_reorder(_lib.ptr(pts), b, N, D, _lib.ptr(picks), m, _lib.ptr(out), _lib.stream()),
+               "facl_fps_reorder")
+    return out
+
+
+def fps_sample_data(points_xyzc, sample_num_level1, sample_num_level2=None, start_idx=None, start_idx2=None, xyz=None):
+    """Reorder every cloud so its FPS picks come first, the remaining rows following in ascending order
+    (np.setdiff1d).  points (b,N,D) CUDA -> new float32 tensor (the reference permutes in place).
+
+    ``sample_num_level2=None``: the 1-level form of cn3D_data_set.py:665-672 (which receives a second count and ignores
+    it).  With ``sample_num_level2`` the 2-level form of cn3d_data_load.py:287-298: the first ``sample_num_level1`` rows
+    are FPS-reordered AGAIN among themselves so that their first ``sample_num_level2`` rows are an FPS subset.
+    ``start_idx`` / ``start_idx2`` (b,) replace the reference's np.random.randint draws (torch's RNG when omitted).
+    ``xyz``: optional (b,N,3) coordinates in the precision the sampling should run in (the reference's clouds are
+    float64; FPS in float32 picks the same rows on tie-free data)."""
     _lib.require_cuda(points_xyzc)
     pts = points_xyzc.contiguous().float()
     b, N, D = pts.shape
+    S1 = int(sample_num_level1)
     if start_idx is None:
         start_idx = torch.randint(0, N, (b,))
-    picks = farthest_point_sampling_batch(pts, sample_num_level1, start_idx)
-    out = torch.empty_like(pts)
-    lib = _lib.load_library()
-    _lib.check(lib.facl_fps_reorder(_lib.ptr(pts), b, N, D, _lib.ptr(picks), sample_num_level1, _lib.ptr(out),
-                                    _lib.stream()), "facl_fps_reorder")
+    src = pts if xyz is None else xyz.contiguous()
+    picks = farthest_point_sampling_batch(src, S1, start_idx)
+    out = _reorder(pts, picks, S1)
+    if sample_num_level2 is None:
+        return out
+    S2 = int(sample_num_level2)
+    if start_idx2 is None:
+        start_idx2 = torch.randint(0, S1, (b,))
+    if xyz is not None:                                   # the level-1 rows in the sampling precision, same permutation
+        src = torch.gather(src, 1, picks.long().unsqueeze(-1).expand(b, S1, src.shape[-1]))
+    else:
+        src = out[:, :S1]
+    picks2 = farthest_point_sampling_batch(src, S2, start_idx2)
+    out[:, :S1] = _reorder(out[:, :S1].contiguous(), picks2, S2)
     return out

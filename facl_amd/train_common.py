@@ -134,7 +134,7 @@ class ContrastiveStep:
         if self.fps_reorder:                                                       # FPS picks first (start index 0)
             from .fps import fps_sample_data
             data1 = fps_sample_data(data1, self.opt.sample_num_level1,
-                                    torch.zeros(data1.shape[0], dtype=torch.int32, device=data1.device))
+                                    start_idx=torch.zeros(data1.shape[0], dtype=torch.int32, device=data1.device))
         xt, yt = self.group(data1)
         x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
         x_keys = fdist.all_gather_view_major(x, G)

@@ -48,10 +48,35 @@ def test_fps_reorder_vs_oracle(dev):
     for N, S in [(512, 64), (2048, 64), (100, 100), (777, 1)]:
         pts = (rng.rand(5, N, 4) - 0.5).astype(np.float32)
         starts = rng.randint(0, N, size=5)
-        out = fps.fps_sample_data(torch.from_numpy(pts).to(dev), S, starts).cpu().numpy()
+        out = fps.fps_sample_data(torch.from_numpy(pts).to(dev), S, start_idx=starts).cpu().numpy()
         np.testing.assert_array_equal(out, OF.fps_sample_data(pts, S, starts))
         # property: a permutation of the rows
         np.testing.assert_array_equal(np.sort(out.reshape(5, -1), axis=1), np.sort(pts.reshape(5, -1), axis=1))
+
+
+def test_fps_reorder_two_level_vs_reference_golden(dev):
+    """HIP 2-level fps_sample_data (cn3d_data_load.py:287-298) against `reorder_out`, the output of the REFERENCE function
+    on float64 clouds with its np.random.randint draws recorded (tools/make_goldens.py: make_fps)."""
+    from facl_amd import fps
+    g = load_golden("fps.npz")
+    pts64 = torch.from_numpy(g["reorder_in"]).to(dev)                      # (2,512,4) float64
+    out = fps.fps_sample_data(pts64, 64, 16, start_idx=g["reorder_s1"], start_idx2=g["reorder_s2"],
+                              xyz=pts64[:, :, :3])                          # sampling in the reference's precision
+    np.testing.assert_array_equal(out.cpu().numpy(), g["reorder_out"].astype(np.float32))
+    # float32 sampling picks the same rows on this (tie-free) cloud
+    out32 = fps.fps_sample_data(pts64.float(), 64, 16, start_idx=g["reorder_s1"], start_idx2=g["reorder_s2"])
+    np.testing.assert_array_equal(out32.cpu().numpy(), g["reorder_out"].astype(np.float32))
+
+
+def test_fps_reorder_two_level_vs_oracle(dev):
+    from facl_amd import fps
+    from oracle import fps as OF
+    rng = np.random.RandomState(5)
+    for N, S1, S2 in [(512, 64, 16), (2048, 128, 32), (100, 100, 100), (300, 7, 1)]:
+        pts = (rng.rand(4, N, 3) - 0.5).astype(np.float32)
+        s1, s2 = rng.randint(0, N, size=4), rng.randint(0, S1, size=4)
+        out = fps.fps_sample_data(torch.from_numpy(pts).to(dev), S1, S2, start_idx=s1, start_idx2=s2).cpu().numpy()
+        np.testing.assert_array_equal(out, OF.fps_sample_data_2level(pts, S1, S2, s1, s2))
 
 
 @pytest.mark.parametrize("tag,r2", [("r016", 0.16), ("r006", 0.06)])

@@ -1,0 +1,126 @@
+"""ONE full contrastive training step at the headline size (BASELINE configs[1]: B=32, T=24, N=2048, D=3) and the same
+through the appearance stream's entry (configs[2]: D=4, appearance-style clouds) against a plain torch-fp64 evaluation
+of the same graph on the GPU (matmuls, train-mode BN with batch statistics, ReLU, max-pools, the reference's literal
+loss construction) -- independent of the HIP kernels and of the size the oracle's goldens pin (C1)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_rel_rows, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4          # north_star: fp32 features / loss within 1e-4 relative
+
+
+def _opt(D, B, N):
+    return SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                           sample_num_level2=64, INPUT_FEATURE_NUM=D, Num_Class=512, batchSize=B,
+                           pooling="concatenation", SAMPLE_NUM=N)
+
+
+def _bn_train64(y, gamma, beta, stats, key):
+    """train-mode BatchNorm over the rows of y (fp64): biased variance to normalise, unbiased one for the running buffer."""
+    P = y.shape[0]
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    stats[key] = (mean, var * (P / (P - 1.0)))
+    return (y - mean) / torch.sqrt(var + 1e-5) * gamma + beta
+
+
+def _forward64(x_rows, centers, sd, G, S, K):
+    """cn3d_model_conbag.py:213-234 in fp64 on (P,D) grouped rows / (M*S,3) centres.  Returns x, x_global, stats."""
+    q = {k: torch.as_tensor(v).to(DEV).double() for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    stats = {}
+    h = x_rows.double()
+    for li in (0, 3, 6):                                                       # net3DV_1 (:43-58)
+        W = q[f"net3DV_1.{li}.weight"].reshape(q[f"net3DV_1.{li}.weight"].shape[0], -1)
+        y = h @ W.t() + q[f"net3DV_1.{li}.bias"]
+        del h
+        h = torch.relu_(_bn_train64(y, q[f"net3DV_1.{li + 1}.weight"], q[f"net3DV_1.{li + 1}.bias"], stats, f"net3DV_1.{li + 1}"))
+        del y
+    MS = h.shape[0] // K
+    pooled = h.view(MS, K, 256).max(dim=1).values
+    del h
+    h = torch.cat((centers.double(), pooled), dim=1)                           # :219
+    for li in (0, 3, 6):                                                       # net3DV_3 (:61-77)
+        W = q[f"net3DV_3.{li}.weight"].reshape(q[f"net3DV_3.{li}.weight"].shape[0], -1)
+        y = h @ W.t() + q[f"net3DV_3.{li}.bias"]
+        h = torch.relu_(_bn_train64(y, q[f"net3DV_3.{li + 1}.weight"], q[f"net3DV_3.{li + 1}.bias"], stats, f"net3DV_3.{li + 1}"))
+    M = MS // S
+    B = M // G
+    local = h.view(M, S, 1024)
+    x_pre = local.max(dim=1).values                                            # :222
+    xg_pre = x_pre.view(G, B, 1024).max(dim=0).values                          # :225-226 (rows are view-major g*B+b)
+
+    def head(t, key):                                                          # netR_FC (:201-207), two BN calls (:228-229)
+        y = t @ q["netR_FC.0.weight"].t() + q["netR_FC.0.bias"]
+        a = torch.relu(_bn_train64(y, q["netR_FC.1.weight"], q["netR_FC.1.bias"], stats, key))
+        return a @ q["netR_FC.3.weight"].t() + q["netR_FC.3.bias"]
+    x = head(x_pre, "fc_a")
+    xg = head(xg_pre, "fc_b")
+    return x, xg, stats, q
+
+
+@pytest.mark.parametrize("stream,D", [("motion", 3), ("appearance", 4)])
+def test_full_step_at_headline_size_vs_torch_fp64(stream, D):
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.train_common import ContrastiveStep, appearance_batch, synthetic_batch
+    from facl_amd.utils_my import knn_radius_group
+    from oracle import loss as OL
+    from oracle.weights import formula_state_dict
+    B, G, N, S, K = 32, 24, 2048, 64, 64
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(11)
+    clip = (appearance_batch if stream == "appearance" else synthetic_batch)(B, G, N, D, torch.device(DEV), gen)
+    opt = _opt(D, B, N)
+    sd = formula_state_dict(D)
+    net = PointNet_Plus(opt, gost=G)
+    net.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    net = net.to(DEV).train()
+    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, fused=True)
+    step = ContrastiveStep(net, optim, opt, G)
+    order = np.random.RandomState(5).permutation(G)
+    # outputs of the step's own forward: hook the model call
+    taps = {}
+    h = net.register_forward_hook(lambda m, i, o: taps.update(x=o[0].detach().clone(), xg=o[3].detach().clone()))
+    loss, loss_c, loss_circle = step(clip, epoch=0, order=order)
+    h.remove()
+    torch.cuda.synchronize()
+
+    # ---- fp64 truth on the same grouped input (the grouping itself is bit-exact integer work: tests/test_gpu_grouping.py)
+    data1 = clip.permute(1, 0, 2, 3).reshape(-1, N, D).float()
+    xt, yt = knn_radius_group(data1, S, K, 0.16)
+    x_rows = xt.permute(0, 2, 3, 1).reshape(-1, D)
+    centers = yt.permute(0, 2, 1, 3).reshape(-1, 3)
+    with torch.no_grad():
+        x64, xg64, stats, q = _forward64(x_rows, centers, sd, G, S, K)
+        lc64 = float(OL.global_contrast(G, xg64, x64, B))                      # the reference's literal logits construction
+        lo64 = float(OL.circle_contrast(G, x64, B, order))
+    e_x = max_rel_rows(taps["x"].cpu().numpy(), x64.cpu().numpy())
+    e_xg = max_rel_rows(taps["xg"].cpu().numpy(), xg64.cpu().numpy())
+    e_lc, e_lo = abs(loss_c.item() - lc64) / abs(lc64), abs(loss_circle.item() - lo64) / abs(lo64)
+    print(f"[{stream}] x {e_x:.2e}  x_global {e_xg:.2e}  loss_c {loss_c.item():.6f} vs {lc64:.6f} ({e_lc:.2e})  "
+          f"loss_circle {loss_circle.item():.6f} vs {lo64:.6f} ({e_lo:.2e})")
+    assert e_x < TOL and e_xg < TOL
+    assert e_lc < TOL and e_lo < TOL
+    assert abs(loss.item() - (lc64 + lo64)) < TOL * abs(lc64 + lo64)
+    # ---- running statistics after the step (momentum 0.1; netR_FC.1 is updated twice: view rows, then clip rows)
+    st = net.state_dict()
+    for key in ("net3DV_1.1", "net3DV_1.4", "net3DV_1.7", "net3DV_3.1", "net3DV_3.4", "net3DV_3.7"):
+        mean, uvar = stats[key]
+        rm = 0.9 * q[f"{key}.running_mean"] + 0.1 * mean
+        rv = 0.9 * q[f"{key}.running_var"] + 0.1 * uvar
+        assert rel_err(st[f"{key}.running_mean"].cpu().numpy(), rm.cpu().numpy()) < 1e-5, key
+        assert rel_err(st[f"{key}.running_var"].cpu().numpy(), rv.cpu().numpy()) < 1e-5, key
+        assert int(st[f"{key}.num_batches_tracked"]) == int(sd[f"{key}.num_batches_tracked"]) + 1
+    rm = 0.9 * (0.9 * q["netR_FC.1.running_mean"] + 0.1 * stats["fc_a"][0]) + 0.1 * stats["fc_b"][0]
+    rv = 0.9 * (0.9 * q["netR_FC.1.running_var"] + 0.1 * stats["fc_a"][1]) + 0.1 * stats["fc_b"][1]
+    assert rel_err(st["netR_FC.1.running_mean"].cpu().numpy(), rm.cpu().numpy()) < 1e-5
+    assert rel_err(st["netR_FC.1.running_var"].cpu().numpy(), rv.cpu().numpy()) < 1e-5
+    assert int(st["netR_FC.1.num_batches_tracked"]) == int(sd["netR_FC.1.num_batches_tracked"]) + 2
+    # ---- the Adam step happened: every parameter that has a gradient moved by <= ~lr, the pre-BN biases did not move
+    for k, p in net.named_parameters():
+        d = (p.detach().cpu().double() - torch.as_tensor(sd[k]).double()).abs().max().item()
+        assert d <= 2 * 3e-4, (k, d)

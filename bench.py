@@ -122,6 +122,7 @@ def kernel_models(a, S=64, K=64):
     M = a.B * a.T
     nunits, D = M * S, a.D
     sa_f32 = os.environ.get("FACL_SA_F32") == "1"
+    bwd2_f32 = os.environ.get("FACL_BWD2_F32") == "1"
     y2 = 64 * 64 * 4                                   # one (64 pos x 64 ch) fp32 tile
     return {
         "facl_group": dict(kernel="k_group", flops=M * S * a.N * 8.0, pipe="valu",
@@ -135,7 +136,7 @@ def kernel_models(a, S=64, K=64):
         "facl_sa_bwd_w3": dict(kernel="k_sa_bwd_w3", pipe="f32", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
                                bytes=nunits * (y2 + 1024.0 + 256.0)),
         # da1 = dy2 W2 (2*64*64) + dW2 += dy2^T a1 (2*64*64) + R1 += [x|1]^T dz1 (2*64*4) per position
-        "facl_sa_bwd2": dict(kernel="k_sa_bwd2", pipe=os.environ.get("FACL_BWD2_PIPE", "f32"),
+        "facl_sa_bwd2": dict(kernel="k_sa_bwd2" if bwd2_f32 else "k_sa_bwd2_sb", pipe="f32" if bwd2_f32 else "bf16x6",
                              flops=nunits * 64.0 * (2 * 64 * 64 + 2 * 64 * 64 + 2 * 64 * 4),
                              bytes=nunits * (2.0 * y2 + 64 * D * 4.0)),
     }

@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256) void k_sa_bwd2(const float* __restrict__ dz2f,
         }
 }
 
+
 }  // namespace
 
 extern "C" int facl_sa_bwd0(const float* dpooled, const float* ymax, int64_t rows, const float* bnc3, float* coef,
@@ -641,12 +642,23 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
     return facl_reduce_rows((const double*)ws, grid, W3_V, out, st);
 }
 
+int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, int nunits, int D, const float* bw2,
+                           const float* W2, const float* l1tab, double* ws, int grid, hipStream_t st);   // sa_bwd2.hip
+
 extern "C" int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nunits, int D,
                             const float* bw2, const float* W2, const float* l1tab, double* out /* 4608 */, void* ws,
                             void* stream) {
     if (!dz2f || !y2f || !x || !bw2 || !W2 || !l1tab || !out || !ws) return FACL_E_NULL;
     if ((D != 3 && D != 4) || nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    // FACL_BWD2_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one
+    static const int use_f32 = getenv("FACL_BWD2_F32") ? atoi(getenv("FACL_BWD2_F32")) : 0;
+    if (!use_f32) {
+        const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 3) / 4 : 2 * SA_GRID);       // 2 workgroups of 4 waves per CU
+        int rc = facl_sa_bwd2_sb_launch(dz2f, y2f, x, (int)nunits, D, bw2, W2, l1tab, (double*)ws, grid, st);
+        if (rc) return rc;
+        return facl_reduce_rows((const double*)ws, grid * 4, B2_V, out, st);
+    }
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
     const size_t lds = (1024 + 128 + 64) * sizeof(float4) + 4 * (2 * 64 * TQ + 64 * 8) * sizeof(float);
     static bool attr_done = false;

@@ -27,6 +27,7 @@ SIGNATURES = {
     "facl_fps_f64": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "facl_fps_reorder": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "facl_group": [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+    "facl_group_clips": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "facl_ws_bytes": [],
     "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],
     "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],
@@ -48,6 +49,9 @@ SIGNATURES = {
     "facl_gemm_dgrad": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_wgrad": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "facl_contrast": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_contrast_pair": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_normalize_map": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p],
+    "facl_scale_rows2": [c_p, c_p, c_l, c_l, c_i, c_p, c_p, c_p],
     "facl_build_views_f32": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "facl_build_views_f64": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "facl_sa_bwd0": [c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
@@ -60,6 +64,7 @@ SIGNATURES = {
     "facl_rows_center_wgrad": [c_p, c_p, c_l, c_i, c_p, c_p, c_p],
     "facl_viewmax_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "facl_viewmax_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "facl_viewmax_bwd_add": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "facl_sa_bwd_final": [c_p] * 13 + [c_i, c_d] + [c_p] * 9 + [c_p],
 }
 RESTYPE_I64 = {"facl_ws_bytes"}

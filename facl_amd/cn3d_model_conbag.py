@@ -11,7 +11,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import sa_mlp
 from . import tail as _tail
@@ -164,15 +163,16 @@ class PointNet_Plus(nn.Module):
         h = _tail.linear_bn_relu(h, self.net3DV_3[3], self.net3DV_3[4], training, self.bn_reduce_fn)
         # last layer fused with my_max_pool (:222-223): xt_local (M,1024,S,1) is never materialised post-BN
         x_pre = _tail.linear_bn_relu_segmax(h, self.net3DV_3[6], self.net3DV_3[7], training, S, self.bn_reduce_fn)
-        # gobaol_max_pool over all gost*S local features of a clip (:225-226) = max over the gost views of
-        # the per-view maxima (rows are view-major: g*B+b)
-        xg_pre = _tail.view_max(x_pre, self.gost)      # first view wins ties, like the reference's max-pool over the sequence
+        # gobaol_max_pool over all gost*S local features of a clip (:225-226) = max over the gost views of the per-view
+        # maxima (rows are view-major: g*B+b; first view wins ties, like the reference's max-pool over the sequence), then
         # :228 x = netR_FC(x_pre), :229 x_global = netR_FC(x_global_pre): one pass over the two Linear layers for both,
-        # BatchNorm statistics (and the two running-statistics updates) per call like the reference
+        # BatchNorm statistics (and the two running-statistics updates) per call like the reference.  The stacked
+        # (M + B, dim) tensor is kept: the training step's loss runs one similarity GEMM on it.
         fc = self.netR_FC
-        x, x_global = _tail.fc_head(x_pre, xg_pre, fc[0], fc[1], fc[3], training, self.bn_reduce_fn)
-        x_nor = F.normalize(x, p=2, dim=1)                                     # :231
-        code = F.linear(x_nor, self.mapping.weight)                            # :232
+        stacked = _tail.fc_head(x_pre, self.gost, fc[0], fc[1], fc[3], training, self.bn_reduce_fn)
+        self._stacked = stacked
+        x, x_global = stacked[:M], stacked[M:]
+        x_nor, code = _tail.normalize_map(x, self.mapping.weight)              # :231-232
         return x, code, x_nor, x_global
 
 

@@ -22,14 +22,18 @@ __device__ __forceinline__ float dist2_exact(float px, float py, float pz, float
 template <int D, int NPL>
 __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict__ points, int N, int S,
                                                          int K, float r2, int32_t* __restrict__ idx_out,
-                                                         float* __restrict__ xt_out, float* __restrict__ yt_out) {
+                                                         float* __restrict__ xt_out, float* __restrict__ yt_out,
+                                                         int clipB) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* ys = xs + N;
     float* zs = ys + N;
     float* cs = zs + N;                       // only when D == 4
     const int m = blockIdx.y;
-    const float* cloud = points + (size_t)m * N * D;
+    // clipB > 0: the input is the loader's (B, G, N, D) clip-major batch and cloud m = g*B + b is read in place (the
+    // permute(1,0,2,3).reshape copy of cn3d_train_motion_GL.py:226 is folded into this address)
+    const size_t src = clipB > 0 ? (size_t)(m % clipB) * (gridDim.y / clipB) + m / clipB : (size_t)m;
+    const float* cloud = points + src * N * D;
 
     // stage the cloud as SoA (conflict-free ds_read_b32 with consecutive lanes on consecutive points)
     for (int i = threadIdx.x; i < N; i += GROUP_THREADS) {
@@ -148,34 +152,45 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
 
 template <int D, int NPL>
 int launch_group(const float* points, int M, int N, int S, int K, float r2, int32_t* idx, float* xt, float* yt,
-                 hipStream_t st) {
+                 int clipB, hipStream_t st) {
     dim3 grid((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M);
     const size_t lds = (size_t)N * 4 * sizeof(float) + 4 * 64 * CKEYS * sizeof(uint32_t);   // cloud (SoA) + one key slot per wave
-    hipLaunchKernelGGL((k_group<D, NPL>), grid, dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt);
+    hipLaunchKernelGGL((k_group<D, NPL>), grid, dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
     return facl_launch_status();
 }
 
 template <int D>
 int dispatch_group(const float* points, int M, int N, int S, int K, float r2, int32_t* idx, float* xt, float* yt,
-                   hipStream_t st) {
-    if (N <= 512) return launch_group<D, 8>(points, M, N, S, K, r2, idx, xt, yt, st);
-    if (N <= 1024) return launch_group<D, 16>(points, M, N, S, K, r2, idx, xt, yt, st);
-    if (N <= 2048) return launch_group<D, 32>(points, M, N, S, K, r2, idx, xt, yt, st);
-    return launch_group<D, 64>(points, M, N, S, K, r2, idx, xt, yt, st);
+                   int clipB, hipStream_t st) {
+    if (N <= 512) return launch_group<D, 8>(points, M, N, S, K, r2, idx, xt, yt, clipB, st);
+    if (N <= 1024) return launch_group<D, 16>(points, M, N, S, K, r2, idx, xt, yt, clipB, st);
+    if (N <= 2048) return launch_group<D, 32>(points, M, N, S, K, r2, idx, xt, yt, clipB, st);
+    return launch_group<D, 64>(points, M, N, S, K, r2, idx, xt, yt, clipB, st);
 }
 
 }  // namespace
 
-extern "C" int facl_group(const float* points, int M, int N, int D, int S, int K, float r2, int32_t* idx,
-                          float* xt, float* yt, void* stream) {
+static int group_entry(const float* points, int M, int N, int D, int S, int K, float r2, int32_t* idx, float* xt,
+                       float* yt, int clipB, void* stream) {
     if (!points) return FACL_E_NULL;
     if (M < 0 || N < 1 || N > 4096 || S < 1 || S > N || K < 1 || K > N || (D != 3 && D != 4)) return FACL_E_SHAPE;
-    if (M > 65535) return FACL_E_SHAPE;
+    if (M > 65535 || clipB < 0 || (clipB > 0 && M % clipB)) return FACL_E_SHAPE;
     if (D == 4 && ((((uintptr_t)points) & 15) || (xt && (((uintptr_t)xt) & 15)))) return FACL_E_ALIGN;
     if (M == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    return D == 4 ? dispatch_group<4>(points, M, N, S, K, r2, idx, xt, yt, st)
-                  : dispatch_group<3>(points, M, N, S, K, r2, idx, xt, yt, st);
+    return D == 4 ? dispatch_group<4>(points, M, N, S, K, r2, idx, xt, yt, clipB, st)
+                  : dispatch_group<3>(points, M, N, S, K, r2, idx, xt, yt, clipB, st);
+}
+
+extern "C" int facl_group(const float* points, int M, int N, int D, int S, int K, float r2, int32_t* idx,
+                          float* xt, float* yt, void* stream) {
+    return group_entry(points, M, N, D, S, K, r2, idx, xt, yt, 0, stream);
+}
+
+extern "C" int facl_group_clips(const float* clips, int B, int G, int N, int D, int S, int K, float r2, int32_t* idx,
+                                float* xt, float* yt, void* stream) {
+    if (B < 1 || G < 1) return FACL_E_SHAPE;
+    return group_entry(clips, B * G, N, D, S, K, r2, idx, xt, yt, B, stream);
 }
 
 extern "C" int facl_version(void) { return (1 << 16) | 0; }

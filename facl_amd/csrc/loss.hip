@@ -164,6 +164,164 @@ __global__ __launch_bounds__(1024) void k_contrast_reg(const float* __restrict__
     if (threadIdx.x == 0) part[n] = loss * (double)invB;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Both losses of a step in ONE launch on ONE similarity matrix.  sim is ((G+1)*B, J) = [x ; x_global] @ keys^T: row
+// block g < G holds view g of the local clips (row g*B + n), block G the clip-level embeddings x_global.  Workgroups
+// 0..B-1 evaluate the global loss of clip n (anchor block G, one positive per view g in column g*Bk + clip), workgroups
+// B..2B-1 the circle loss (anchor blocks order[0..G-2], positive of slot i in block order[i], column order[i+1]*Bk + clip;
+// block order[G-1] is no anchor: its dsim row is zeroed here so that every row of dsim is written exactly once).
+// The anchors gather, the positive-column index tensors and the second similarity GEMM of the two-call form disappear.
+struct PairSpec {
+    int nA, nS, slot_rows, circle, G, B, Bk, J, myclip, n;
+    const long long* order;
+    __device__ __forceinline__ int row_block(int i) const { return circle ? (int)order[i] : G; }
+    __device__ __forceinline__ size_t pos_index(int s) const {
+        const int rb = row_block(slot_rows ? s : 0);
+        const int col = (circle ? (int)order[s + 1] : s) * Bk + myclip;
+        return (size_t)(rb * B + n) * J + col;
+    }
+};
+
+__global__ __launch_bounds__(1024) void k_contrast_pair_reg(const float* __restrict__ sim, int G, int B, int Bk, int J,
+                                                           const long long* __restrict__ order, int clip_offset,
+                                                           float* __restrict__ dsim, double* __restrict__ part) {
+    __shared__ float smf[16];
+    __shared__ double smd[16];
+    __shared__ int rb_s[1024];
+    PairSpec sp;
+    sp.circle = blockIdx.x >= (unsigned)B;
+    sp.n = sp.circle ? blockIdx.x - B : blockIdx.x;
+    sp.nA = sp.circle ? G - 1 : 1; sp.nS = sp.circle ? G - 1 : G; sp.slot_rows = sp.circle;
+    sp.G = G; sp.B = B; sp.Bk = Bk; sp.J = J; sp.myclip = sp.n + clip_offset; sp.order = order;
+    const int n = sp.n, myclip = sp.myclip, nA = sp.nA, nS = sp.nS;
+    if ((int)threadIdx.x < nA) rb_s[threadIdx.x] = sp.row_block(threadIdx.x);
+    __syncthreads();
+    const int total = nA * J;
+    float v[CK];
+    float mx = 0.f;                                        // masked entries are 0, there is at least one
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const int e = threadIdx.x + k * 1024;
+        float x = 0.f;                                     // beyond the end: behaves like a masked column
+        if (e < total) {
+            const int i = e / J, j = e - i * J;
+            x = (j % Bk == myclip) ? 0.f : sim[(size_t)(rb_s[i] * B + n) * J + j];
+        }
+        v[k] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = block_reduce_max(mx, smf);
+    double se = 0;
+#pragma unroll
+    for (int k = 0; k < CK; ++k)
+        if ((int)threadIdx.x + k * 1024 < total) se += (double)__expf(v[k] - mx);
+    se = block_reduce_sum(se, smd);
+    const float lse = mx + (float)log(se);
+    double loss_t = 0, dlse_t = 0;
+    float dpos = 0.f;
+    size_t ppos = 0;
+    const float invB = 1.f / (float)B;
+    for (int s = threadIdx.x; s < nS; s += 1024) {       // nS <= 1024: at most one trip per thread
+        ppos = sp.pos_index(s);
+        const float pos = sim[ppos];
+        const float m2 = fmaxf(pos, lse);
+        const float t = m2 + log1pf(__expf(-fabsf(pos - lse)));
+        loss_t += (double)(t - pos);
+        dlse_t += (double)(1.f - __expf(pos - t));
+        dpos = (__expf(pos - t) - 1.f) * invB;
+    }
+    const double loss = block_reduce_sum(loss_t, smd);
+    const float dlse = (float)block_reduce_sum(dlse_t, smd) * invB;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const int e = threadIdx.x + k * 1024;
+        if (e < total) {
+            const int i = e / J, j = e - i * J;
+            dsim[(size_t)(rb_s[i] * B + n) * J + j] = (j % Bk == myclip) ? 0.f : dlse * __expf(v[k] - lse);
+        }
+    }
+    if (sp.circle) {                                       // the view that is no anchor: zero gradient row
+        float* z = dsim + (size_t)((int)order[G - 1] * B + n) * J;
+        for (int j = threadIdx.x; j < J; j += 1024) z[j] = 0.f;
+    }
+    __syncthreads();                                       // the positives overwrite zeros written just above
+    if ((int)threadIdx.x < nS) dsim[ppos] = dpos;
+    if (threadIdx.x == 0) part[2 * n + sp.circle] = loss * (double)invB;
+}
+
+// streaming form for shapes the register-cached kernel cannot hold ((G-1)*J > CK*1024 or G > 1024)
+__global__ __launch_bounds__(256) void k_contrast_pair(const float* __restrict__ sim, int G, int B, int Bk, int J,
+                                                       const long long* __restrict__ order, int clip_offset,
+                                                       float* __restrict__ dsim, double* __restrict__ part) {
+    __shared__ float smf[4];
+    __shared__ double smd[4];
+    PairSpec sp;
+    sp.circle = blockIdx.x >= (unsigned)B;
+    sp.n = sp.circle ? blockIdx.x - B : blockIdx.x;
+    sp.nA = sp.circle ? G - 1 : 1; sp.nS = sp.circle ? G - 1 : G; sp.slot_rows = sp.circle;
+    sp.G = G; sp.B = B; sp.Bk = Bk; sp.J = J; sp.myclip = sp.n + clip_offset; sp.order = order;
+    const int n = sp.n, myclip = sp.myclip, nA = sp.nA, nS = sp.nS;
+    float mx = 0.f;
+    for (int i = 0; i < nA; ++i) {
+        const float* row = sim + (size_t)(sp.row_block(i) * B + n) * J;
+        for (int j = threadIdx.x; j < J; j += 256) mx = fmaxf(mx, (j % Bk == myclip) ? 0.f : row[j]);
+    }
+    mx = block_reduce_max(mx, smf);
+    double se = 0;
+    for (int i = 0; i < nA; ++i) {
+        const float* row = sim + (size_t)(sp.row_block(i) * B + n) * J;
+        for (int j = threadIdx.x; j < J; j += 256) se += (double)__expf(((j % Bk == myclip) ? 0.f : row[j]) - mx);
+    }
+    se = block_reduce_sum(se, smd);
+    const float lse = mx + (float)log(se);
+    float dlse = 0.f;
+    double loss = 0;
+    for (int s = 0; s < nS; ++s) {
+        const float pos = sim[sp.pos_index(s)];
+        const float t = fmaxf(pos, lse) + log1pf(__expf(-fabsf(pos - lse)));
+        loss += (double)(t - pos);
+        dlse += (1.f - __expf(pos - t));
+    }
+    const float invB = 1.f / (float)B;
+    dlse *= invB;
+    for (int i = 0; i < nA; ++i) {
+        const size_t ro = (size_t)(sp.row_block(i) * B + n) * J;
+        for (int j = threadIdx.x; j < J; j += 256) dsim[ro + j] = (j % Bk == myclip) ? 0.f : dlse * __expf(sim[ro + j] - lse);
+    }
+    if (sp.circle) {
+        float* z = dsim + (size_t)((int)order[G - 1] * B + n) * J;
+        for (int j = threadIdx.x; j < J; j += 256) z[j] = 0.f;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nS; s += 256) {
+        const size_t pp = sp.pos_index(s);
+        const float pos = sim[pp];
+        const float t = fmaxf(pos, lse) + log1pf(__expf(-fabsf(pos - lse)));
+        dsim[pp] = (__expf(pos - t) - 1.f) * invB;
+    }
+    if (threadIdx.x == 0) part[2 * n + sp.circle] = loss * (double)invB;
+}
+
+// dst[r][:] = src[r][:] * (r < R1 ? *g1 : *g2): the chain rule of the two loss values onto the shared d/dsim matrix
+template <typename V>
+__global__ __launch_bounds__(256) void k_scale_rows2(const V* __restrict__ src, V* __restrict__ dst, long long n,
+                                                     long long split, const float* __restrict__ g1,
+                                                     const float* __restrict__ g2) {
+    const float a = *g1, b = *g2;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float g = i < split ? a : b;
+        if constexpr (sizeof(V) == 16) {
+            float4 v = src[i];
+            v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+            dst[i] = v;
+        } else {
+            dst[i] = src[i] * g;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int facl_contrast(const float* sim, int R, int J, int B, int Bk, int nA, int nS, int slot_rows,
@@ -182,4 +340,37 @@ extern "C" int facl_contrast(const float* sim, int R, int J, int B, int Bk, int 
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, B, 1, loss, st);
+}
+
+extern "C" int facl_contrast_pair(const float* sim, int G, int B, int Bk, int J, const int64_t* order, int clip_offset,
+                                  float* dsim, double* losses /* [loss_c, loss_circle] */, void* ws, void* stream) {
+    if (!sim || !order || !dsim || !losses || !ws) return FACL_E_NULL;
+    if (G < 2 || B < 1 || Bk < 1 || J != G * Bk) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024)
+        hipLaunchKernelGGL(k_contrast_pair_reg, dim3(2 * B), dim3(1024), 0, st, sim, G, B, Bk, J, (const long long*)order,
+                           clip_offset, dsim, (double*)ws);
+    else
+        hipLaunchKernelGGL(k_contrast_pair, dim3(2 * B), dim3(256), 0, st, sim, G, B, Bk, J, (const long long*)order,
+                           clip_offset, dsim, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, B, 2, losses, st);
+}
+
+extern "C" int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J, const float* g1, const float* g2,
+                                void* stream) {
+    if (!src || !dst || !g1 || !g2) return FACL_E_NULL;
+    if (R1 < 0 || R1 > R || R < 1 || J < 1) return FACL_E_SHAPE;
+    const long long n = R * (long long)J, split = R1 * (long long)J;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(n & 3) && !(split & 3) && !((((uintptr_t)src) | ((uintptr_t)dst)) & 15)) {
+        const long long n4 = n / 4;
+        const int grid = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+        hipLaunchKernelGGL((k_scale_rows2<float4>), dim3(grid), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4, split / 4, g1, g2);
+    } else {
+        const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+        hipLaunchKernelGGL((k_scale_rows2<float>), dim3(grid), dim3(256), 0, st, src, dst, n, split, g1, g2);
+    }
+    return facl_launch_status();
 }

@@ -289,6 +289,64 @@ __global__ __launch_bounds__(256) void k_viewmax_bwd(const float* __restrict__ d
             make_float4(a.x == g ? d.x : 0.f, a.y == g ? d.y : 0.f, a.z == g ? d.z : 0.f, a.w == g ? d.w : 0.f);
 }
 
+// F.normalize(p=2, dim=1, eps=1e-12) + mapping (Linear C -> K, no bias): one workgroup of 256 threads per row.
+// The row is normalised into LDS; thread t then owns output k = t >> 2 (+64 per pass) and a quarter of the C columns.
+__global__ __launch_bounds__(256) void k_normalize_map(const float* __restrict__ x, int C, const float* __restrict__ Wm,
+                                                       int K, float* __restrict__ xn, float* __restrict__ code) {
+    __shared__ __attribute__((aligned(16))) float row[4096];
+    __shared__ float red[4];
+    const size_t m = blockIdx.x;
+    const float4* xr = reinterpret_cast<const float4*>(x + m * C);
+    const int C4 = C >> 2;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < C4; i += 256) {
+        const float4 v = xr[i];
+        reinterpret_cast<float4*>(row)[i] = v;
+        ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    }
+    ss = wave_sum_f32(ss);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    float4* xo = reinterpret_cast<float4*>(xn + m * C);
+    for (int i = threadIdx.x; i < C4; i += 256) {
+        float4 v = reinterpret_cast<float4*>(row)[i];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        reinterpret_cast<float4*>(row)[i] = v;
+        xo[i] = v;
+    }
+    __syncthreads();
+    const int qtr = threadIdx.x & 3, q4 = C4 >> 2;          // quarter of the row: float4s [qtr*q4, (qtr+1)*q4)
+    for (int k = threadIdx.x >> 2; k < K; k += 64) {
+        const float4* w = reinterpret_cast<const float4*>(Wm + (size_t)k * C) + qtr * q4;
+        const float4* r = reinterpret_cast<const float4*>(row) + qtr * q4;
+        float acc = 0.f;
+        for (int i = 0; i < q4; ++i) {
+            const float4 a = r[i], b = w[i];
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (qtr == 0) code[m * K + k] = acc;
+    }
+}
+
+// dx (G*B, C) += dout routed to the winning view's row (the rows of dx already hold the other gradient path of x_pre)
+__global__ __launch_bounds__(256) void k_viewmax_bwd_add(const float* __restrict__ dout, const int* __restrict__ arg,
+                                                         int B, int C4, float* __restrict__ dx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C4) return;
+    const int b = i / C4, c4 = i - b * C4;
+    const float4 d = reinterpret_cast<const float4*>(dout)[i];
+    const int4 a = reinterpret_cast<const int4*>(arg)[i];
+    const size_t C = (size_t)C4 * 4, col = (size_t)c4 * 4;
+    dx[((size_t)a.x * B + b) * C + col + 0] += d.x;
+    dx[((size_t)a.y * B + b) * C + col + 1] += d.y;
+    dx[((size_t)a.z * B + b) * C + col + 2] += d.z;
+    dx[((size_t)a.w * B + b) * C + col + 3] += d.w;
+}
+
 int rows_grid_y(int R, int C) {
     int gx = (C + 255) / 256;
     int gy = ROWS_BLOCKS / gx;
@@ -427,5 +485,24 @@ extern "C" int facl_viewmax_bwd(const float* dout, const int32_t* arg, int G, in
     if ((((uintptr_t)dout) | ((uintptr_t)dx) | ((uintptr_t)arg)) & 15) return FACL_E_ALIGN;
     const int n = B * (C / 4);
     hipLaunchKernelGGL(k_viewmax_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, arg, G, B, C / 4, dx);
+    return facl_launch_status();
+}
+
+extern "C" int facl_normalize_map(const float* x, int64_t M, int C, const float* Wm, int K, float* x_nor, float* code,
+                                  void* stream) {
+    if (!x || !Wm || !x_nor || !code) return FACL_E_NULL;
+    if (M < 0 || M > 0x7fffffff || C < 16 || (C & 15) || C > 4096 || K < 1 || K > 256) return FACL_E_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)Wm) | ((uintptr_t)x_nor)) & 15) return FACL_E_ALIGN;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(k_normalize_map, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, C, Wm, K, x_nor, code);
+    return facl_launch_status();
+}
+
+extern "C" int facl_viewmax_bwd_add(const float* dout, const int32_t* arg, int G, int B, int C, float* dx, void* stream) {
+    if (!dout || !arg || !dx) return FACL_E_NULL;
+    if (G < 1 || B < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
+    if ((((uintptr_t)dout) | ((uintptr_t)arg)) & 15) return FACL_E_ALIGN;
+    const int n = B * (C / 4);
+    hipLaunchKernelGGL(k_viewmax_bwd_add, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, arg, B, C / 4, dx);
     return facl_launch_status();
 }

@@ -235,21 +235,33 @@ class _Linear(torch.autograd.Function):
 
 
 class _FCHead(torch.autograd.Function):
-    """netR_FC (Linear -> BatchNorm1d -> ReLU -> Linear, cn3d_model_conbag.py:201-207) applied to the per-view rows AND
-    to the per-clip rows (:228-229) in one pass: the two Linear layers run ONCE on the stacked rows (the second call has
-    only B rows -- 16 workgroups for a 1024x1024 layer, latency-bound), while BatchNorm keeps the reference's two
-    separate batch statistics and its two sequential running-statistics updates, segment by segment."""
+    """gobaol_max_pool (cn3d_model_conbag.py:225-226) + netR_FC (Linear -> BatchNorm1d -> ReLU -> Linear, :201-207) applied
+    to the per-view rows AND to the per-clip rows (:228-229) in one pass.
+
+    x_pre (G*B, C) view-major -> ONE stacked output (G*B + B, dim): rows [0, G*B) = netR_FC(x_pre) = ``x``, rows
+    [G*B, G*B + B) = netR_FC(max over the G views) = ``x_global``.  The two Linear layers run ONCE on the stacked rows (the
+    second call alone has only B rows -- 16 workgroups for a 1024x1024 layer, latency-bound), while BatchNorm keeps the
+    reference's two separate batch statistics and its two sequential running-statistics updates, segment by segment.
+    Keeping the stacked tensor whole lets the loss run ONE similarity GEMM on it (utils_my._ContrastivePair) and spares
+    the cat / split launches of both directions; in the backward the view-max gradient is scattered straight into the
+    rows of dL/dx_pre (no (G*B, C) zero tensor, no autograd accumulation kernel)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, W1, b1, gamma, beta, bn, W2, b2, training, reduce_fn):
+    def forward(ctx, x_pre, G, W1, b1, gamma, beta, bn, W2, b2, training, reduce_fn):
         lib = _lib.load_library()
-        _lib.require_cuda(xa, xb)
-        ws = _Workspace.get(xa.device)
-        h = torch.cat((xa, xb), dim=0)
+        _lib.require_cuda(x_pre)
+        ws = _Workspace.get(x_pre.device)
+        x_pre = x_pre.contiguous()
+        M, Cin = x_pre.shape
+        B = M // G
+        h = torch.empty((M + B, Cin), dtype=torch.float32, device=x_pre.device)
+        h[:M].copy_(x_pre)
+        arg = torch.empty((B, Cin), dtype=torch.int32, device=x_pre.device)
+        _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, Cin, h[M:].data_ptr(), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
         W1, W2 = W1.contiguous(), W2.contiguous()
         y, _ = gemm_fwd(h, W1, b1)
         R, C = y.shape
-        segs = ((0, xa.shape[0]), (xa.shape[0], R))
+        segs = ((0, M), (M, R))
         a = torch.empty_like(y)
         bncs, counts = [], []
         if training:
@@ -275,19 +287,19 @@ class _FCHead(torch.autograd.Function):
             bncs.append(bnc)
             counts.append(count)
         out, _ = gemm_fwd(a, W2, b2)
-        ctx.save_for_backward(h, W1, y, a, W2, *bncs)
-        ctx.segs, ctx.counts, ctx.reduce_fn, ctx.training = segs, counts, reduce_fn, training
-        return out[:segs[0][1]], out[segs[0][1]:]
+        ctx.save_for_backward(h, W1, y, a, W2, arg, *bncs)
+        ctx.segs, ctx.counts, ctx.reduce_fn, ctx.training, ctx.G = segs, counts, reduce_fn, training, G
+        return out
 
     @staticmethod
-    def backward(ctx, da_out, db_out):
+    def backward(ctx, dout):
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
-        h, W1, y, a, W2, bnc_a, bnc_b = ctx.saved_tensors
+        h, W1, y, a, W2, arg, bnc_a, bnc_b = ctx.saved_tensors
         ws = _Workspace.get(y.device)
         R, C = y.shape
-        dout = torch.cat((da_out, db_out), dim=0)
+        dout = dout.contiguous()
         dW2 = gemm_wgrad(dout, a)
         db2 = dout.sum(0)
         dact = gemm_dgrad(dout, W2)
@@ -307,15 +319,52 @@ class _FCHead(torch.autograd.Function):
         dgamma, dbeta = dga[0] + dga[1], dbe[0] + dbe[1]
         dW1 = gemm_wgrad(dy, h)
         dh = gemm_dgrad(dy, W1)
-        na = ctx.segs[0][1]
+        M = ctx.segs[0][1]
+        B = R - M
+        # dL/dx_pre = dh[:M] + (dh[M:] routed to the winning view's row of each (clip, channel))
+        _lib.check(lib.facl_viewmax_bwd_add(dh[M:].data_ptr(), _lib.ptr(arg), ctx.G, B, dh.shape[1], _lib.ptr(dh), _lib.stream()),
+                   "facl_viewmax_bwd_add")
         # d(bias of the first Linear) is identically zero in front of a train-mode BN: None leaves it untouched
-        return dh[:na], dh[na:], dW1, None, dgamma, dbeta, None, dW2, db2, None, None
+        return dh[:M], None, dW1, None, dgamma, dbeta, None, dW2, db2, None, None
 
 
-def fc_head(xa, xb, affine1, bn, affine2, training, reduce_fn=None):
-    """(netR_FC(xa), netR_FC(xb)) with the reference's two BatchNorm calls and ONE pass over each Linear layer."""
-    return _FCHead.apply(xa, xb, affine1.weight, affine1.bias, bn.weight, bn.bias, bn, affine2.weight, affine2.bias,
+def fc_head(x_pre, G, affine1, bn, affine2, training, reduce_fn=None):
+    """Stacked [netR_FC(x_pre) ; netR_FC(gobaol_max_pool(x_pre))] ((G*B + B, dim)): the reference's two BatchNorm calls,
+    ONE pass over each Linear layer."""
+    return _FCHead.apply(x_pre, G, affine1.weight, affine1.bias, bn.weight, bn.bias, bn, affine2.weight, affine2.bias,
                          training, reduce_fn)
+
+
+class _NormalizeMap(torch.autograd.Function):
+    """x_nor = F.normalize(x, p=2, dim=1), code = mapping(x_nor) (cn3d_model_conbag.py:231-232) as one HIP kernel.  The
+    live loss does not use these outputs; the backward (SwAV branch, user code) is the closed form in tensor algebra."""
+
+    @staticmethod
+    def forward(ctx, x, Wm):
+        lib = _lib.load_library()
+        _lib.require_cuda(x)
+        x, Wm = x.contiguous(), Wm.contiguous()
+        M, C = x.shape
+        K = Wm.shape[0]
+        xn = torch.empty_like(x)
+        code = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        _lib.check(lib.facl_normalize_map(_lib.ptr(x), M, C, _lib.ptr(Wm), K, _lib.ptr(xn), _lib.ptr(code), _lib.stream()),
+                   "facl_normalize_map")
+        ctx.save_for_backward(x, xn, Wm)
+        return xn, code
+
+    @staticmethod
+    def backward(ctx, dxn, dcode):
+        x, xn, Wm = ctx.saved_tensors
+        dxn_t = dcode @ Wm if dxn is None else dxn + dcode @ Wm
+        dWm = dcode.t() @ xn
+        nrm = x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        dx = (dxn_t - xn * (dxn_t * xn).sum(1, keepdim=True)) / nrm
+        return dx, dWm
+
+
+def normalize_map(x, mapping_weight):
+    return _NormalizeMap.apply(x, mapping_weight)
 
 
 class _ViewMax(torch.autograd.Function):

@@ -11,7 +11,7 @@ import torch
 
 from . import cn3d_model_conbag as MODELL
 from . import dist as fdist
-from .utils_my import contrastive_losses, group_points_3DV, knn_radius_group
+from .utils_my import contrastive_losses_stacked, group_points_3DV, knn_radius_group
 
 
 def build_parser(default_branch):
@@ -114,7 +114,7 @@ class ContrastiveStep:
             return group_points_3DV(data1, opt)                                   # :230 (K=64, r^2=0.06 literals)
         r2 = self.r2 if self.r2 is not None else 0.16                             # group_points_3DV_2048's literal
         opt.INPUT_FEATURE_NUM = data1.shape[-1]
-        return knn_radius_group(data1, opt.sample_num_level1, opt.knn_K, r2)
+        return knn_radius_group(data1, opt.sample_num_level1, opt.knn_K, r2)     # (M,N,D) or clip-major (B,G,N,D)
 
     def __call__(self, out_points, epoch=0, order=None):
         netR, G = self.netR, self.G
@@ -130,17 +130,21 @@ class ContrastiveStep:
         """Device-only body (no host round trips): this is what GraphedStep captures into a HIP graph."""
         netR, G = self.netR, self.G
         B, G_, N, D = out_points.shape
-        data1 = out_points.permute(1, 0, 2, 3).reshape(-1, N, D).float()          # :226-228 (view-major rows)
-        if self.fps_reorder:                                                       # FPS picks first (start index 0)
-            from .fps import fps_sample_data
-            data1 = fps_sample_data(data1, self.opt.sample_num_level1,
-                                    start_idx=torch.zeros(data1.shape[0], dtype=torch.int32, device=data1.device))
-        xt, yt = self.group(data1)
+        if self.fps_reorder or out_points.dtype != torch.float32 or (self.r2 is None and self.opt.SAMPLE_NUM == 512):
+            data1 = out_points.permute(1, 0, 2, 3).reshape(-1, N, D).float()      # :226-228 (view-major rows)
+            if self.fps_reorder:                                                   # FPS picks first (start index 0)
+                from .fps import fps_sample_data
+                data1 = fps_sample_data(data1, self.opt.sample_num_level1,
+                                        start_idx=torch.zeros(data1.shape[0], dtype=torch.int32, device=data1.device))
+            xt, yt = self.group(data1)
+        else:
+            xt, yt = self.group(out_points)        # clip-major batch: the grouping kernel reads view-major in place
         x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
         x_keys = fdist.all_gather_view_major(x, G)
         off = self.rank * B
         # global (:265-287) + circle (:290-316) losses: similarity GEMMs + one HIP kernel each (csrc/loss.hip)
-        loss_c, loss_circle = contrastive_losses(G, x_global, x, order, x_keys=x_keys, clip_offset=off)
+        loss_c, loss_circle = contrastive_losses_stacked(G, netR._stacked, order, x_keys=None if x_keys is x else x_keys,
+                                                         clip_offset=off)
         loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()

@@ -13,11 +13,15 @@ def knn_radius_group(points, sample_num_level1, knn_K, ball_radius, want_idx=Fal
     """points (M,N,D) float32 CUDA -> (inputs_level1 (M,D,S,K) view, center (M,3,S,1) view[, idx]).
 
     The returned tensors are transposed VIEWS of contiguous (M,S,K,D) / (M,S,3) buffers, exactly
-    like the reference's (utils_my.py:283-284).  ``points`` is not modified."""
+    like the reference's (utils_my.py:283-284).  ``points`` is not modified.
+    A 4-D ``points`` (B,G,N,D) is the loader's clip-major batch: the outputs are those of
+    ``points.permute(1,0,2,3).reshape(G*B,N,D)`` (cn3d_train_motion_GL.py:226) without materialising that copy."""
     _lib.require_cuda(points)
     if points.dtype != torch.float32:
         raise TypeError("points must be float32 (the reference casts with .type(torch.FloatTensor))")
     pts = points.contiguous()
+    if pts.dim() == 4:
+        return _knn_radius_group_clips(pts, sample_num_level1, knn_K, ball_radius, want_idx)
     M, N, D = pts.shape
     S, K = int(sample_num_level1), int(knn_K)
     xt = torch.empty((M, S, K, D), dtype=torch.float32, device=pts.device)
@@ -32,6 +36,20 @@ def knn_radius_group(points, sample_num_level1, knn_K, ball_radius, want_idx=Fal
     if want_idx:
         return inputs_level1, inputs_level1_center, idx
     return inputs_level1, inputs_level1_center
+
+
+def _knn_radius_group_clips(clips, sample_num_level1, knn_K, ball_radius, want_idx):
+    B, G, N, D = clips.shape
+    M, S, K = B * G, int(sample_num_level1), int(knn_K)
+    xt = torch.empty((M, S, K, D), dtype=torch.float32, device=clips.device)
+    yt = torch.empty((M, S, 3), dtype=torch.float32, device=clips.device)
+    idx = torch.empty((M, S, K), dtype=torch.int32, device=clips.device) if want_idx else None
+    lib = _lib.load_library()
+    with _lib.timed("facl_group"):
+        _lib.check(lib.facl_group_clips(_lib.ptr(clips), B, G, N, D, S, K, float(ball_radius), _lib.ptr(idx), _lib.ptr(xt),
+                                        _lib.ptr(yt), _lib.stream()), "facl_group_clips")
+    out = (xt.permute(0, 3, 1, 2), yt.view(M, 1, S, 3).transpose(1, 3))
+    return out + (idx,) if want_idx else out
 
 
 def group_points_3DV(points, opt):
@@ -186,6 +204,65 @@ class _ContrastiveLosses(torch.autograd.Function):
         d_x = torch.zeros(G, B, C, dtype=keys.dtype, device=keys.device)
         d_x.index_add_(0, order[:-1], d_anchors.view(G - 1, B, C))
         return d_xg, d_x.view(G * B, C), d_keys, None, None, None
+
+
+class _ContrastivePair(torch.autograd.Function):
+    """(loss_c, loss_circle) from the stacked embeddings [x ; x_global] ((G+1)*B rows): ONE similarity GEMM
+    sim = stacked @ keys^T on the hand-written MFMA GEMM, ONE loss launch (facl_contrast_pair: both values and
+    d/dsim, the circle anchors addressed through ``order`` instead of gathered), and in the backward one dgrad
+    (d stacked = dsim @ keys) plus one wgrad (d keys = dsim^T @ stacked).  No library GEMM, no anchors gather, no
+    positive-column index tensors, no index_add (utils_my.py:63-71,100-103 and their autograd)."""
+
+    @staticmethod
+    def forward(ctx, stacked, keys, order, G, clip_offset):
+        from . import tail as _tail
+        from .sa_mlp import _Workspace
+        lib = _lib.load_library()
+        _lib.require_cuda(stacked, keys)
+        dev = stacked.device
+        ws = _Workspace.get(dev)
+        stacked = stacked.contiguous()
+        R, C = stacked.shape
+        B = R // (G + 1)
+        ctx.own_keys = keys is None                # single process: the keys ARE the view rows of `stacked`
+        keys = stacked[:G * B] if keys is None else keys.contiguous()
+        J = keys.shape[0]
+        Bk = J // G
+        ctx.mfma = (J % 4 == 0 and C % 4 == 0)     # the MFMA GEMMs contract over multiples of 4; odd toy shapes: library GEMM
+        sim = _tail.gemm_fwd(stacked, keys, None)[0] if ctx.mfma else stacked @ keys.t()     # ((G+1)B, J)  :71 and :103
+        dsim = torch.empty_like(sim)
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        _lib.check(lib.facl_contrast_pair(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), clip_offset, _lib.ptr(dsim),
+                                          _lib.ptr(out), _lib.ptr(ws), _lib.stream()), "facl_contrast_pair")
+        ctx.save_for_backward(stacked, keys, dsim)
+        ctx.GB = G * B
+        out32 = out.float()
+        return out32[0], out32[1]
+
+    @staticmethod
+    def backward(ctx, g_c, g_o):
+        from . import tail as _tail
+        stacked, keys, dsim = ctx.saved_tensors
+        # rows [0, G*B) carry the circle loss, rows [G*B, (G+1)*B) the global loss: one scaling launch for both
+        lib = _lib.load_library()
+        ds = torch.empty_like(dsim)
+        R, J = dsim.shape
+        _lib.check(lib.facl_scale_rows2(_lib.ptr(dsim), _lib.ptr(ds), ctx.GB, R, J, _lib.ptr(g_o.contiguous().float()),
+                                        _lib.ptr(g_c.contiguous().float()), _lib.stream()), "facl_scale_rows2")
+        d_stacked = _tail.gemm_dgrad(ds, keys) if ctx.mfma else ds @ keys
+        d_keys = _tail.gemm_wgrad(ds, stacked) if ctx.mfma else ds.t() @ stacked
+        if ctx.own_keys:
+            d_stacked[:ctx.GB] += d_keys
+            d_keys = None
+        return d_stacked, d_keys, None, None, None
+
+
+def contrastive_losses_stacked(num_crop, stacked, order, x_keys=None, clip_offset=0):
+    """(loss_c, loss_circle) from the model's stacked output [x ; x_global] (facl_amd.cn3d_model_conbag: ``_stacked``)."""
+    G = num_crop
+    if not (torch.is_tensor(order) and order.device == stacked.device and order.dtype == torch.long):
+        order = torch.as_tensor(order, device=stacked.device, dtype=torch.long)
+    return _ContrastivePair.apply(stacked, x_keys, order.contiguous(), G, clip_offset)
 
 
 def contrastive_losses(num_crop, x_global, x, order, x_keys=None, clip_offset=0):

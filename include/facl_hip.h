@@ -65,6 +65,10 @@ int facl_fps_reorder(const float* points, int M, int N, int D, const int32_t* pi
  * Supported: S <= N <= 4096, 1 <= K <= N. */
 int facl_group(const float* points, int M, int N, int D, int S, int K, float r2,
                int32_t* idx, float* xt, float* yt, void* stream);
+/* The same on the loader's clip-major batch: clips (B,G,N,D) contiguous; outputs are view-major, cloud m = g*B + b
+ * (the permute(1,0,2,3).reshape(-1,N,D) copy of cn3d_train_motion_GL.py:226 is folded into the kernel's addressing). */
+int facl_group_clips(const float* clips, int B, int G, int N, int D, int S, int K, float r2, int32_t* idx,
+                     float* xt, float* yt, void* stream);
 
 /* ---- train-mode BatchNorm plumbing (fp64) -------------------------------------------------
  * BN semantics: cn3d_model_conbag.py:46,50,54,64,68,72,84 (nn.BatchNorm2d/1d defaults).
@@ -150,7 +154,7 @@ int facl_sa_bwd_final(const double* out3, const double* sums0_g, const double* s
 
 /* ---- encoder tail: row-major (R,C) BatchNorm / ReLU / max-over-S kernels ----------------------
  * net3DV_3 + my_max_pool + netR_FC (cn3d_model_conbag.py:61-88, :199-207).  The dense contractions
- * between them are plain library GEMMs (rocBLAS through torch.mm); these kernels are everything else.
+ * between them are the facl_gemm_* entries below (hand-written MFMA GEMMs); these kernels are everything else.
  * bnc = (5,C) constants of facl_bn_finalize / facl_bn_eval_consts; kk = (2,C) = (dbeta/P, dgamma/P).
  *   facl_rows_stats        y (R,C) -> sums (C,2)
  *   facl_rows_bn_relu      out = relu(scale*y + shift)                         (may run in place)
@@ -171,6 +175,9 @@ int facl_rows_bwd_stats(const float* dout, const float* y, int64_t R, int C, con
  * of dx (G*B,C) and writes zeros elsewhere. */
 int facl_viewmax_fwd(const float* x, int G, int B, int C, float* out, int32_t* arg, void* stream);
 int facl_viewmax_bwd(const float* dout, const int32_t* arg, int G, int B, int C, float* dx, void* stream);
+/* the same routing ADDED into dx (G*B,C), whose rows already hold the other gradient path of x_pre (each (clip, channel)
+ * touches exactly one element: no atomics) */
+int facl_viewmax_bwd_add(const float* dout, const int32_t* arg, int G, int B, int C, float* dx, void* stream);
 /* dWc (C,3) fp64 = dy^T centers: the centroid-xyz columns of the first per-centroid layer's weight gradient
  * (the input of net3DV_3 is torch.cat((yt, xt), 1), cn3d_model_conbag.py:219) in one streaming pass over dy */
 int facl_rows_center_wgrad(const float* dy, const float* centers, int64_t R, int C, double* dWc, void* ws,
@@ -213,6 +220,23 @@ int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, in
  * clip_offset = rank*B under data parallelism.  Outputs: loss (1 double), dsim (R,J) = d loss / d sim. */
 int facl_contrast(const float* sim, int R, int J, int B, int Bk, int nA, int nS, int slot_rows,
                   const int32_t* poscol, int clip_offset, float* dsim, double* loss, void* ws, void* stream);
+/* Both losses of a training step (cn3d_train_motion_GL.py:265-316) in one launch on ONE similarity matrix
+ * sim ((G+1)*B, J) = [x ; x_global] @ keys^T (row block g < G: view g of the local clips, block G: x_global; J = G*Bk).
+ * order (G) int64 = the circle loss's view permutation (utils_my.py:96-97).  losses = [loss_c, loss_circle];
+ * dsim ((G+1)*B, J) = d(loss_c + loss_circle)/d sim, every row written (the block of view order[G-1], which is no
+ * anchor, is zero). */
+int facl_contrast_pair(const float* sim, int G, int B, int Bk, int J, const int64_t* order, int clip_offset,
+                       float* dsim, double* losses, void* ws, void* stream);
+/* dst (R,J) = src scaled by *g1 in rows [0,R1) and by *g2 in rows [R1,R): the two upstream gradients (device scalars)
+ * of loss_circle / loss_c applied to the shared d/dsim matrix. */
+int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J, const float* g1, const float* g2,
+                     void* stream);
+
+/* ---- F.normalize + mapping (cn3d_model_conbag.py:231-232) --------------------------------------
+ * x (M,C) -> x_nor = x / max(||x||_2, 1e-12) row-wise, code (M,K) = x_nor @ Wm^T (Wm (K,C), no bias).
+ * C % 4 == 0, C <= 4096, K <= 256. */
+int facl_normalize_map(const float* x, int64_t M, int C, const float* Wm, int K, float* x_nor, float* code,
+                       void* stream);
 
 /* ---- view construction of a batch of clips (replaces the NumPy pipeline of
  * training_code/cn3D_data_set.py:285-350 get_data_train + :654-663 + :708-713 + :734-749 + :767-778 and the

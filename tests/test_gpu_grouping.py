@@ -79,6 +79,20 @@ def test_fps_reorder_two_level_vs_oracle(dev):
         np.testing.assert_array_equal(out, OF.fps_sample_data_2level(pts, S1, S2, s1, s2))
 
 
+@pytest.mark.parametrize("B,G,N,D", [(3, 4, 512, 4), (2, 5, 2048, 3), (1, 1, 100, 3)])
+def test_group_clip_major_equals_permuted_copy(dev, B, G, N, D):
+    """facl_group_clips on the loader's (B,G,N,D) batch == facl_group on permute(1,0,2,3).reshape(G*B,N,D)
+    (cn3d_train_motion_GL.py:226), bit for bit."""
+    from facl_amd import utils_my
+    torch.manual_seed(B * G + N)
+    clips = (torch.rand(B, G, N, D, device=dev) - 0.5)
+    S, K = min(64, N), min(64, N)
+    a = utils_my.knn_radius_group(clips, S, K, 0.1, want_idx=True)
+    b = utils_my.knn_radius_group(clips.permute(1, 0, 2, 3).reshape(-1, N, D).contiguous(), S, K, 0.1, want_idx=True)
+    for ta, tb in zip(a, b):
+        assert ta.shape == tb.shape and ta.stride() == tb.stride() and torch.equal(ta, tb)
+
+
 @pytest.mark.parametrize("tag,r2", [("r016", 0.16), ("r006", 0.06)])
 def test_group_tiny_golden(dev, tag, r2):
     from facl_amd import utils_my

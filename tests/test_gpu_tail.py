@@ -58,3 +58,63 @@ def test_final_fc_against_reference_fixture():
     np.testing.assert_allclose(net.fc.weight.grad.reshape(-1)[:4096].cpu().numpy(), g["gradhead_weight"], rtol=1e-3, atol=1e-7)
     gn = float(net.fc.weight.grad.double().norm())
     assert abs(gn - float(g["gradnorm_weight"])) < 1e-4 * float(g["gradnorm_weight"])
+
+
+@pytest.mark.parametrize("M,C,K", [(800, 512, 64), (5, 512, 64), (33, 64, 7)])
+def test_normalize_map_vs_torch(M, C, K):
+    """facl_normalize_map == F.normalize(x, p=2, dim=1) + F.linear (cn3d_model_conbag.py:231-232), forward and backward
+    (fp64 torch as truth), including an all-zero row (eps clamp)."""
+    import torch.nn.functional as F
+    from facl_amd import tail
+    torch.manual_seed(M)
+    x = torch.randn(M, C, device=DEV) * 3.0
+    x[M // 2] = 0.0
+    Wm = torch.randn(K, C, device=DEV) * 0.05
+    xa, wa = x.clone().requires_grad_(True), Wm.clone().requires_grad_(True)
+    xn, code = tail.normalize_map(xa, wa)
+    xr, wr = x.double().requires_grad_(True), Wm.double().requires_grad_(True)
+    xn_r = F.normalize(xr, p=2, dim=1)
+    code_r = F.linear(xn_r, wr)
+    assert float((xn.double() - xn_r).abs().max()) < 1e-6
+    assert float((code.double() - code_r).abs().max()) < 1e-5
+    g1, g2 = torch.randn_like(xn), torch.randn_like(code)
+    ((xn * g1).sum() + (code * g2).sum()).backward()
+    ((xn_r * g1.double()).sum() + (code_r * g2.double()).sum()).backward()
+    keep = torch.ones(M, dtype=torch.bool, device=DEV)
+    keep[M // 2] = False                                     # d/dx at x = 0 is not defined (torch returns 0/eps terms)
+    assert float((xa.grad.double() - xr.grad)[keep].norm() / xr.grad[keep].norm()) < 1e-5
+    assert float((wa.grad.double() - wr.grad).norm() / wr.grad.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("G,B,C,world", [(6, 5, 32, 1), (24, 32, 512, 1), (4, 3, 16, 2), (10, 4, 512, 1)])
+def test_contrastive_pair_on_stacked_embeddings_vs_closed_form_fp64(G, B, C, world):
+    """utils_my._ContrastivePair (one similarity GEMM on [x ; x_global], facl_contrast_pair, dgrad + wgrad) vs the
+    device-agnostic closed form of global_contrast / circle_contrast in fp64: both values and the gradients wrt the
+    stacked embeddings, single-process (keys = the view rows themselves) and data-parallel (gathered keys) forms."""
+    from facl_amd.utils_my import circle_contrast, contrastive_losses_stacked, global_contrast
+    torch.manual_seed(G * B + C)
+    Bk, off = B * world, B * (world - 1)
+    keys0 = (torch.randn(G, Bk, C, dtype=torch.float64) * 0.3).to(DEV)
+    x0 = keys0[:, off:off + B].reshape(G * B, C).clone()
+    xg0 = (torch.randn(B, C, dtype=torch.float64) * 0.3).to(DEV)
+    order = np.random.RandomState(1).permutation(G)
+
+    def keys_of(x, dtype):
+        k = keys0.to(dtype).clone()
+        k[:, off:off + B] = x.view(G, B, C)
+        return k.reshape(G * Bk, C)
+
+    x64, xg64 = x0.clone().requires_grad_(True), xg0.clone().requires_grad_(True)
+    k64 = keys_of(x64, torch.float64) if world > 1 else None
+    lc_r = global_contrast(G, xg64, x64, None, x_keys=k64, clip_offset=off)
+    lo_r = circle_contrast(G, x64, B, order=order, x_keys=k64, clip_offset=off)
+    gr = torch.autograd.grad(0.7 * lc_r + 1.3 * lo_r, (xg64, x64))
+    st = torch.cat((x0, xg0), 0).float().requires_grad_(True)
+    k32 = keys_of(st[:G * B], torch.float32) if world > 1 else None
+    lc, lo = contrastive_losses_stacked(G, st, order, x_keys=k32, clip_offset=off)
+    (0.7 * lc + 1.3 * lo).backward()                        # distinct upstream gradients exercise facl_scale_rows2
+    assert abs(float(lc) - float(lc_r)) <= 2e-6 * abs(float(lc_r))
+    assert abs(float(lo) - float(lo_r)) <= 2e-6 * abs(float(lo_r))
+    g = st.grad.double()
+    assert float((g[:G * B] - gr[1]).norm() / gr[1].norm()) < 2e-5
+    assert float((g[G * B:] - gr[0]).norm() / gr[0].norm()) < 2e-5

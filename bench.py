@@ -118,8 +118,9 @@ def _pmc_traffic(a, kernel):
 # neighbour positions; nunits = M*S.  pipe "f32": v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s, algorithmic FLOPs);
 # pipe "bf16x6": exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16 -- 6 executed bf16 FLOPs per algorithmic one, priced
 # against the 2.5 PFLOP/s dense bf16 peak.
-def kernel_models(a, S=64, K=64):
+def kernel_models(a, K=64):
     M = a.B * a.T
+    S = 512 if a.config == "dense" else 64             # level-1 centroids per cloud (facl_amd/dense.py: S1)
     nunits, D = M * S, a.D
     sa_f32 = os.environ.get("FACL_SA_F32") == "1"
     bwd2_f32 = os.environ.get("FACL_BWD2_F32") == "1"
@@ -143,11 +144,13 @@ def kernel_models(a, S=64, K=64):
 
 
 def _gemm_model(label):
-    kind, dims = label.split()
+    parts = label.split()
+    kind, dims = parts[0], parts[1]
     m, k, n = (int(v) for v in dims.split("x"))
-    pipe = "f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6"
+    pipe = "f16" if len(parts) > 2 else ("f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6")
     name = {"facl_gemm_fwd": "k_gemm_sb fwd", "facl_gemm_dgrad": "k_gemm_sb dgrad", "facl_gemm_wgrad": "k_gemm_sb wgrad"}[kind]
-    return dict(kernel="%s %s" % (name, dims), pipe=pipe, flops=2.0 * m * k * n, bytes=4.0 * (m * k + k * n + m * n))
+    return dict(kernel="%s %s%s" % (name, dims, " (fp16 inputs)" if pipe == "f16" else ""), pipe=pipe, flops=2.0 * m * k * n,
+                bytes=4.0 * (m * k + k * n + m * n))
 
 
 def price(model, ms):

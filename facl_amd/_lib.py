@@ -28,6 +28,8 @@ SIGNATURES = {
     "facl_fps_reorder": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "facl_group": [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "facl_group_clips": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+    "facl_gather_rows": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p],
+    "facl_scatter_rows": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "facl_ws_bytes": [],
     "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],
     "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],
@@ -48,6 +50,10 @@ SIGNATURES = {
     "facl_gemm_fwd_segmax": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_wgrad": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "facl_gemm_fwd_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_gemm_fwd_segmax_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_dgrad_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
+    "facl_gemm_wgrad_f16": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "facl_contrast": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_contrast_pair": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_normalize_map": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p],

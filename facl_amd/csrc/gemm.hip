@@ -41,6 +41,7 @@ struct GemmArgs {
     // fused max over each block of 64 consecutive rows (my_max_pool over the S = 64 centroids of a cloud): per
     // (row block, column) max of sgn[j]*C and the FIRST row that attains it; 128x128 tiles only.  Null when unused.
     const float* sgn; float* smax; int* sarg;
+    int prec;                          // 0: fp32 result (bf16x6 or fp32 MFMA), 1: fp16 inputs, one MFMA product, fp32 accumulate
 };
 
 template <int LAY, int T>
@@ -447,15 +448,24 @@ __device__ __forceinline__ void load_tile_ic8(const float* __restrict__ P, int l
 // Staging is two-phase so that the conversion overlaps the MFMAs: split_tile_* turns the raw fp32 registers of the
 // NEXT stage into packed bf16 planes (VALU only, scheduled between the MFMAs of the current stage), write_tile_*
 // is the bare LDS store between the two workgroup barriers.  PK = 12T packed registers per operand.
-template <int T>
+// NP = 3: exact 3-way bf16 split; NP = 1: one fp16 plane (round to nearest), for the fp16-input MFMA
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(float x0, float x1) {
+    const f32x2v v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
+}
+template <int T, int NP>
 __device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned (&pk)[12 * T]) {
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
+        for (int j = 0; j < 4; ++j) {
+            if (NP == 3) split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
+            else pk[12 * i + j] = pk_f16(r[8 * i + 2 * j], r[8 * i + 2 * j + 1]);
+        }
 }
-template <int T>
+template <int T, int NP>
 __device__ __forceinline__ void write_tile_ic8(unsigned short* __restrict__ S, const unsigned (&pk)[12 * T], int tid) {
     constexpr int PLANE = 64 * T * SBROW;
     const int il = tid % (64 * T), kc = tid / (64 * T);
@@ -463,13 +473,13 @@ __device__ __forceinline__ void write_tile_ic8(unsigned short* __restrict__ S, c
     for (int i = 0; i < T; ++i) {
         unsigned short* d = S + il * SBROW + 8 * (kc + (4 / T) * i);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
             *reinterpret_cast<uint4*>(d + p * PLANE) =
                 make_uint4(pk[12 * i + 4 * p], pk[12 * i + 4 * p + 1], pk[12 * i + 4 * p + 2], pk[12 * i + 4 * p + 3]);
     }
 }
 
-template <bool PRO, int T>
+template <bool PRO, int T, int NP>
 __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigned (&pk)[12 * T], int tid, int k0,
                                                const float* __restrict__ ps, const float* __restrict__ pt) {
 #pragma unroll
@@ -482,23 +492,28 @@ __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigne
             v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
             v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
         }
-        split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
-        split_pair(v[2], v[3], pk[6 * i + 1], pk[6 * i + 3], pk[6 * i + 5]);
+        if (NP == 3) {
+            split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
+            split_pair(v[2], v[3], pk[6 * i + 1], pk[6 * i + 3], pk[6 * i + 5]);
+        } else {
+            pk[6 * i] = pk_f16(v[0], v[1]);
+            pk[6 * i + 1] = pk_f16(v[2], v[3]);
+        }
     }
 }
-template <int T>
+template <int T, int NP>
 __device__ __forceinline__ void write_tile_kc4(unsigned short* __restrict__ S, const unsigned (&pk)[12 * T], int tid) {
     constexpr int PLANE = 64 * T * SBROW;
 #pragma unroll
     for (int i = 0; i < 2 * T; ++i) {
         unsigned short* d = S + ((tid >> 3) + 32 * i) * SBROW + 4 * (tid & 7);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * PLANE) = make_uint2(pk[6 * i + 2 * p], pk[6 * i + 2 * p + 1]);
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + p * PLANE) = make_uint2(pk[6 * i + 2 * p], pk[6 * i + 2 * p + 1]);
     }
 }
 
 
-template <int LA, int LB, bool PRO, int TM, int TN>
+template <int LA, int LB, bool PRO, int TM, int TN, int NP = 3>
 __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int APL = BM * SBROW, BPL = BN * SBROW;                   // one bf16 plane of each operand (elements)
@@ -540,29 +555,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
     };
     unsigned pka[12 * TM], pkb[12 * TN];
     auto split = [&](int k0) {
-        if (LA == KC) split_tile_kc4<PRO, TM>(ra4, pka, tid, k0, g.pscale, g.pshift);
-        else split_tile_ic8<TM>(ra8, pka);
-        if (LB == KC) split_tile_kc4<false, TN>(rb4, pkb, tid, k0, nullptr, nullptr);
-        else split_tile_ic8<TN>(rb8, pkb);
+        if (LA == KC) split_tile_kc4<PRO, TM, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
+        else split_tile_ic8<TM, NP>(ra8, pka);
+        if (LB == KC) split_tile_kc4<false, TN, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
+        else split_tile_ic8<TN, NP>(rb8, pkb);
     };
     auto write = [&]() {
-        if (LA == KC) write_tile_kc4<TM>(sA, pka, tid);
-        else write_tile_ic8<TM>(sA, pka, tid);
-        if (LB == KC) write_tile_kc4<TN>(sB, pkb, tid);
-        else write_tile_ic8<TN>(sB, pkb, tid);
+        if (LA == KC) write_tile_kc4<TM, NP>(sA, pka, tid);
+        else write_tile_ic8<TM, NP>(sA, pka, tid);
+        if (LB == KC) write_tile_kc4<TN, NP>(sB, pkb, tid);
+        else write_tile_ic8<TN, NP>(sB, pkb, tid);
     };
     auto mfma_block = [&](int kk) {
-        bf16x8 af[TM][3], bf[TN][3];
+        bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * APL + (32 * TM * wr + 32 * a + q) * SBROW + 16 * kk + 8 * h);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 bf[b][p] = *reinterpret_cast<const bf16x8*>(sB + p * BPL + (32 * TN * wc + 32 * b + q) * SBROW + 16 * kk + 8 * h);
+        if constexpr (NP == 1) {                                        // fp16 inputs: ONE product per multiply-add
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[a][0]),
+                                                                       __builtin_bit_cast(f16x8, bf[b][0]), acc[a][b], 0, 0, 0);
+            return;
+        }
         // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
         constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
 #pragma unroll
@@ -570,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][PA[t]], bf[b][PB[t]], acc[a][b]);
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][NP == 3 ? PA[t] : 0], bf[b][NP == 3 ? PB[t] : 0], acc[a][b]);
     };
     fetch(kbeg);
     split(kbeg);
@@ -624,6 +648,18 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     static const int use_dma = getenv("FACL_GEMM_DMA") ? atoi(getenv("FACL_GEMM_DMA")) : 1;
     // FACL_GEMM_F32=1 selects the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split-bf16 ones
     static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
+    if (g.prec == 1) {                                                  // fp16-input MFMA, fp32 accumulation
+        if (big >= 256) {
+            dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2, 1>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 64;
+        } else {
+            dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1, 1>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 32;
+        }
+        return facl_launch_status();
+    }
     if (!use_f32) {
         if (big >= 256) {
             dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
@@ -659,15 +695,15 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
 }  // namespace
 
 // y (M,N) = opA(a) W^T + bias (+ centres term), optional BN+ReLU prologue on a, optional column statistics
-extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
-                             const float* pscale, const float* pshift, const float* centers, const float* Wc,
-                             int ldwc, float* y, double* sums, void* ws, void* stream) {
+static int gemm_fwd_p(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                      const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                      int ldwc, float* y, double* sums, void* ws, void* stream, int prec) {
     if (!a || !W || !y || (sums && !ws)) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || K < 4 || (K & 3) || N < 1 || (ldw & 3)) return FACL_E_SHAPE;
     if ((pscale == nullptr) != (pshift == nullptr) || (centers == nullptr) != (Wc == nullptr)) return FACL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, pscale, pshift, centers, Wc, ldwc,
-               sums ? (double*)ws : nullptr, K, nullptr, nullptr, nullptr};
+               sums ? (double*)ws : nullptr, K, nullptr, nullptr, nullptr, prec};
     int rpp = 64;
     int rc = pscale ? launch<KC, KC, true>(g, 1, st, &rpp) : launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
@@ -681,15 +717,15 @@ extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, i
 // facl_gemm_fwd + my_max_pool over blocks of S = 64 consecutive rows fused into the epilogue: ymax (M/64,N) =
 // max_s sgn[j]*y, arg = first s that attains it (BN + ReLU are monotone per channel, so the pooled activation follows
 // from ymax once the statistics are final: facl_sa_pool).  Saves the 201 MB re-read of y by facl_rows_segmax.
-extern "C" int facl_gemm_fwd_segmax(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
-                                    const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
-                                    void* stream) {
+static int gemm_fwd_segmax_p(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                             const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                             void* stream, int prec) {
     if (!a || !W || !y || !sgn || !ymax || !arg || (sums && !ws)) return FACL_E_NULL;
     if (M < 64 || M > 0x7fffffff || (M & 63) || K < 4 || (K & 3) || N < 1 || (ldw & 3)) return FACL_E_SHAPE;
     if ((long long)((N + 127) / 128) * ((M + 127) / 128) < 256) return FACL_E_CONFIG;    // needs the 128x128 tiles
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, nullptr, nullptr, nullptr, nullptr, 0,
-               sums ? (double*)ws : nullptr, K, sgn, ymax, arg};
+               sums ? (double*)ws : nullptr, K, sgn, ymax, arg, prec};
     int rpp = 64;
     int rc = launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
@@ -699,28 +735,65 @@ extern "C" int facl_gemm_fwd_segmax(const float* a, int64_t M, int K, const floa
 }
 
 // da (M,K) = dy (M,N) W (N,K)        (W row-major with leading dimension ldw; pass W + offset to skip columns)
-extern "C" int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
-                               void* stream) {
+static int gemm_dgrad_p(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
+                        void* stream, int prec) {
     if (!dy || !W || !da) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 1) return FACL_E_SHAPE;
-    GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N, nullptr, nullptr, nullptr};
+    GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N, nullptr, nullptr, nullptr, prec};
     return launch<KC, IC, false>(g, 1, (hipStream_t)stream, nullptr);
 }
 
 // dW (N,K) = dy^T (N,M) a (M,K), split over nz row chunks; `slices` is scratch for nz*N*K floats
-extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
-                               float* slices, int nz, void* stream) {
+static int gemm_wgrad_p(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                        float* slices, int nz, void* stream, int prec) {
     if (!dy || !a || !dW || !slices) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     int kchunk = (int)((M + nz - 1) / nz);
     kchunk = (kchunk + BK - 1) / BK * BK;
     nz = (int)((M + kchunk - 1) / kchunk);
-    GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr};
+    GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr, prec};
     int rc = launch<IC, IC, false>(g, nz, st, nullptr);
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_sum_slices, dim3(grid), dim3(256), 0, st, slices, nz, n4, dW);
     return facl_launch_status();
+}
+
+// ---- C ABI: fp32-result entries and their fp16-input twins (same arguments; inputs rounded to fp16 while staged, one
+// v_mfma_f32_32x32x16_f16 product per multiply-add, fp32 accumulation and storage) ----------------------------------------
+extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                             const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                             int ldwc, float* y, double* sums, void* ws, void* stream) {
+    return gemm_fwd_p(a, M, K, W, ldw, N, bias, pscale, pshift, centers, Wc, ldwc, y, sums, ws, stream, 0);
+}
+extern "C" int facl_gemm_fwd_f16(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                                 const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                                 int ldwc, float* y, double* sums, void* ws, void* stream) {
+    return gemm_fwd_p(a, M, K, W, ldw, N, bias, pscale, pshift, centers, Wc, ldwc, y, sums, ws, stream, 1);
+}
+extern "C" int facl_gemm_fwd_segmax(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                                    const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                                    void* stream) {
+    return gemm_fwd_segmax_p(a, M, K, W, ldw, N, bias, sgn, y, sums, ymax, arg, ws, stream, 0);
+}
+extern "C" int facl_gemm_fwd_segmax_f16(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                                        const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                                        void* stream) {
+    return gemm_fwd_segmax_p(a, M, K, W, ldw, N, bias, sgn, y, sums, ymax, arg, ws, stream, 1);
+}
+extern "C" int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da, void* stream) {
+    return gemm_dgrad_p(dy, M, N, W, ldw, K, da, stream, 0);
+}
+extern "C" int facl_gemm_dgrad_f16(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da, void* stream) {
+    return gemm_dgrad_p(dy, M, N, W, ldw, K, da, stream, 1);
+}
+extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                               float* slices, int nz, void* stream) {
+    return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 0);
+}
+extern "C" int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                                   float* slices, int nz, void* stream) {
+    return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 1);
 }

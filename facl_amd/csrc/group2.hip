@@ -1,0 +1,95 @@
+// Second-level grouping on channel-first features (utils_my.py:332-381, group_points_2 / group_points_2_3DV): the kNN +
+// radius rule runs on the level-1 centroid coordinates through facl_group (group.hip: same select, same exact-tie rule,
+// idx and centred xyz out); this file moves the FEATURES: a row gather by those indices (forward) and its transpose,
+// a deterministic scatter-add (backward).  Features live row-major, (M, S1, C) -- the layout the level-1 pooling
+// writes and the level-2 point-MLP GEMM reads; the reference's channel-first (M, 3+C, S2, K) tensor is a permuted view
+// of the gathered rows (facl_amd/dense.py).
+// Roofline: HBM.  Forward bytes per output row = 4*C read + 4*C (+12) written; the dense configuration's level 2
+// (M*S2*K = 2.1 M rows of 256 channels per 8 clips) moves 4.3 GB per step in this kernel pair.
+#include "common.h"
+
+namespace {
+
+// out[r][col_off + c] = feat[m][idx[r]][c]; with xyz != nullptr also out[r][0..2] = xyz[r][0..2] (col_off = 3)
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ feat, int ldf, int S1, int C,
+                                                     const int32_t* __restrict__ idx, long long rows, int rows_per_cloud,
+                                                     const float* __restrict__ xyz, float* __restrict__ out, int ldo,
+                                                     int col_off) {
+    const int lane = threadIdx.x & 63;
+    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    for (long long r = w0; r < rows; r += nw) {
+        const long long m = r / rows_per_cloud;
+        const int id = idx[r];                                           // wave-uniform
+        const float* src = feat + ((size_t)m * S1 + id) * ldf;
+        float* dst = out + (size_t)r * ldo + col_off;
+        if (VEC) {
+            for (int c4 = lane; c4 < (C >> 2); c4 += 64)
+                reinterpret_cast<float4*>(dst)[c4] = reinterpret_cast<const float4*>(src)[c4];
+        } else {
+            for (int c = lane; c < C; c += 64) dst[c] = src[c];
+        }
+        if (xyz && lane < 3) out[(size_t)r * ldo + lane] = xyz[(size_t)r * 3 + lane];
+    }
+}
+
+// d_feat[m][s][c] = sum over the rows r of cloud m with idx[r] == s of drows[r][col_off + c].  One single-wave workgroup
+// per (cloud, 64-channel chunk): an LDS accumulator [S1][64] (lane = channel: no two lanes ever touch one word), the
+// cloud's rows added in index order -> deterministic, no atomics.
+__global__ __launch_bounds__(64) void k_scatter_rows(const float* __restrict__ drows, int ldd, int col_off, int C,
+                                                     const int32_t* __restrict__ idx, int rows_per_cloud, int S1,
+                                                     float* __restrict__ dfeat) {
+    extern __shared__ float acc[];                                       // [S1][64]
+    const int lane = threadIdx.x, m = blockIdx.y, c = blockIdx.x * 64 + lane;
+    for (int i = lane; i < S1 * 64; i += 64) acc[i] = 0.f;
+    const int32_t* ix = idx + (size_t)m * rows_per_cloud;
+    const float* src = drows + (size_t)m * rows_per_cloud * ldd + col_off + c;
+    const bool on = c < C;
+    int r = 0;
+    for (; r + 8 <= rows_per_cloud; r += 8) {                            // 8 independent loads in flight, adds in order
+        float v[8];
+        int id[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { id[j] = ix[r + j]; v[j] = on ? src[(size_t)(r + j) * ldd] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[id[j] * 64 + lane] += v[j];
+    }
+    for (; r < rows_per_cloud; ++r) acc[ix[r] * 64 + lane] += on ? src[(size_t)r * ldd] : 0.f;
+    if (on)
+        for (int s = 0; s < S1; ++s) dfeat[((size_t)m * S1 + s) * C + c] = acc[s * 64 + lane];
+}
+
+}  // namespace
+
+extern "C" int facl_gather_rows(const float* feat, int ldf, int M, int S1, int C, const int32_t* idx, int rows_per_cloud,
+                                const float* xyz, float* out, int ldo, int col_off, void* stream) {
+    if (!feat || !idx || !out) return FACL_E_NULL;
+    if (M < 0 || S1 < 1 || C < 1 || rows_per_cloud < 1 || ldf < C || col_off < 0 || ldo < col_off + C) return FACL_E_SHAPE;
+    if (xyz && col_off < 3) return FACL_E_SHAPE;
+    if (M == 0) return 0;
+    const long long rows = (long long)M * rows_per_cloud;
+    const bool vec = !(C & 3) && !(ldf & 3) && !(ldo & 3) && !(col_off & 3) && !((((uintptr_t)feat) | ((uintptr_t)out)) & 15);
+    const int grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL((k_gather_rows<true>), dim3(grid), dim3(256), 0, st, feat, ldf, S1, C, idx, rows, rows_per_cloud, xyz, out, ldo, col_off);
+    else hipLaunchKernelGGL((k_gather_rows<false>), dim3(grid), dim3(256), 0, st, feat, ldf, S1, C, idx, rows, rows_per_cloud, xyz, out, ldo, col_off);
+    return facl_launch_status();
+}
+
+extern "C" int facl_scatter_rows(const float* drows, int ldd, int col_off, int M, int S1, int C, const int32_t* idx,
+                                 int rows_per_cloud, float* dfeat, void* stream) {
+    if (!drows || !idx || !dfeat) return FACL_E_NULL;
+    if (M < 0 || S1 < 1 || C < 1 || rows_per_cloud < 1 || col_off < 0 || ldd < col_off + C) return FACL_E_SHAPE;
+    if ((size_t)S1 * 64 * sizeof(float) > 160 * 1024 || M > 65535) return FACL_E_SHAPE;
+    if (M == 0) return 0;
+    const size_t lds = (size_t)S1 * 64 * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_scatter_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(k_scatter_rows, dim3((C + 63) / 64, M), dim3(64), lds, (hipStream_t)stream, drows, ldd, col_off, C, idx,
+                       rows_per_cloud, S1, dfeat);
+    return facl_launch_status();
+}

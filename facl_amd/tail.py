@@ -11,6 +11,50 @@ from . import _lib
 from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize, _plus_minus_one
 
 
+# ---- arithmetic of the dense contractions -------------------------------------------------------------------------------
+# "f32": fp32-grade results (exact 3-way bf16 split on the bf16 MFMA, or the fp32 MFMA with FACL_GEMM_F32=1);
+# "f16": fp16-input MFMA with fp32 accumulation (dense configuration).  The precision in force when a layer's FORWARD
+# runs is recorded on its autograd context and used again by its backward GEMMs.
+_PRECISION = ["f32"]
+
+
+class precision:
+    def __init__(self, p):
+        if p not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        self.p = p
+
+    def __enter__(self):
+        _PRECISION.append(self.p)
+        return self
+
+    def __exit__(self, *exc):
+        _PRECISION.pop()
+        return False
+
+
+def current_precision():
+    return _PRECISION[-1]
+
+
+class _PrecGuard:
+    """Scope guard for backward(): restores the precision when the frame that created it returns (or raises)."""
+
+    def __init__(self, p):
+        _PRECISION.append(p)
+
+    def __del__(self):
+        _PRECISION.pop()
+
+
+def _plabel():
+    return " f16" if _PRECISION[-1] == "f16" else ""
+
+
+def _fn(lib, name):
+    return getattr(lib, name + "_f16") if _PRECISION[-1] == "f16" else getattr(lib, name)
+
+
 def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
     """y = a W^T + bias [+ centers Wc^T] on the hand-written fp32 MFMA GEMM (csrc/gemm.hip); optional fused
     column (sum, sumsq) for the BatchNorm that follows."""
@@ -20,8 +64,8 @@ def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
     y = torch.empty((M, N), dtype=torch.float32, device=a.device)
     sums = torch.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
     ws = _Workspace.get(a.device)
-    with _lib.timed("facl_gemm_fwd %dx%dx%d" % (M, K, N)):
-        _lib.check(lib.facl_gemm_fwd(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
+    with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (M, K, N, _plabel())):
+        _lib.check(_fn(lib, "facl_gemm_fwd")(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
                                      _lib.ptr(centers), _lib.ptr(Wc), 3 if Wc is not None else 0, _lib.ptr(y),
                                      _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_gemm_fwd")
     return y, sums
@@ -33,8 +77,8 @@ def gemm_dgrad(dy, W):
     M, N = dy.shape
     K = W.shape[1]
     da = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-    with _lib.timed("facl_gemm_dgrad %dx%dx%d" % (M, N, K)):
-        _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
+    with _lib.timed("facl_gemm_dgrad %dx%dx%d%s" % (M, N, K, _plabel())):
+        _lib.check(_fn(lib, "facl_gemm_dgrad")(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
                    "facl_gemm_dgrad")
     return da
 
@@ -48,8 +92,8 @@ def gemm_wgrad(dy, a):
     nz = max(1, min((M + 255) // 256, 512 // tiles))     # tiles * nz = one resident wave of workgroups (2 per CU)
     dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = torch.empty(nz * N * K, dtype=torch.float32, device=dy.device)
-    with _lib.timed("facl_gemm_wgrad %dx%dx%d" % (M, N, K)):
-        _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
+    with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _plabel())):
+        _lib.check(_fn(lib, "facl_gemm_wgrad")(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
                                        _lib.stream()), "facl_gemm_wgrad")
     return dW
 
@@ -95,6 +139,7 @@ class _LinearBNReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, W, b, gamma, beta, bn, training, reduce_fn, centers=None):
+        ctx.prec = current_precision()
         lib = _lib.load_library()
         _lib.require_cuda(h)
         ws = _Workspace.get(h.device)
@@ -118,6 +163,7 @@ class _LinearBNReLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da):
+        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
@@ -148,6 +194,7 @@ class _LinearBNSegmax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, W, b, gamma, beta, bn, training, reduce_fn, S):
+        ctx.prec = current_precision()
         lib = _lib.load_library()
         _lib.require_cuda(h)
         ws = _Workspace.get(h.device)
@@ -165,8 +212,8 @@ class _LinearBNSegmax(torch.autograd.Function):
             y = torch.empty((R, C), dtype=torch.float32, device=h.device)
             sums = torch.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
             ymax = torch.empty((M, C), dtype=torch.float32, device=h.device)
-            with _lib.timed("facl_gemm_fwd %dx%dx%d" % (R, h.shape[1], C)):
-                rc = lib.facl_gemm_fwd_segmax(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b),
+            with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (R, h.shape[1], C, _plabel())):
+                rc = _fn(lib, "facl_gemm_fwd_segmax")(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b),
                                               _lib.ptr(sgn), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(ymax), _lib.ptr(arg),
                                               _lib.ptr(ws), _lib.stream())
             if rc == 0:
@@ -188,6 +235,7 @@ class _LinearBNSegmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxpre, _darg):
+        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
@@ -222,6 +270,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, W, b):
+        ctx.prec = current_precision()
         h, W = h.contiguous(), W.contiguous()
         y, _ = gemm_fwd(h, W, b)
         ctx.save_for_backward(h, W)
@@ -229,6 +278,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
         h, W = ctx.saved_tensors
         dy = dy.contiguous()
         return gemm_dgrad(dy, W), gemm_wgrad(dy, h), dy.sum(0)
@@ -248,6 +298,7 @@ class _FCHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_pre, G, W1, b1, gamma, beta, bn, W2, b2, training, reduce_fn):
+        ctx.prec = current_precision()
         lib = _lib.load_library()
         _lib.require_cuda(x_pre)
         ws = _Workspace.get(x_pre.device)
@@ -293,6 +344,7 @@ class _FCHead(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()

@@ -210,6 +210,30 @@ int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, 
                     void* stream);
 int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                     float* slices, int nz, void* stream);
+/* fp16-input twins (dense configuration, BASELINE configs[4] "fp16 MFMA point-MLP"): same arguments and fp32 storage;
+ * the operands are rounded to fp16 while their tiles are staged and every multiply-add is ONE
+ * v_mfma_f32_32x32x16_f16 product with fp32 accumulation (instead of the six bf16 products of the fp32-grade path). */
+int facl_gemm_fwd_f16(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                      const float* pscale, const float* pshift, const float* centers, const float* Wc, int ldwc,
+                      float* y, double* sums, void* ws, void* stream);
+int facl_gemm_fwd_segmax_f16(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                             const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                             void* stream);
+int facl_gemm_dgrad_f16(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
+                        void* stream);
+int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                        float* slices, int nz, void* stream);
+
+/* ---- second-level grouping on channel-first features (utils_my.py:332-381 group_points_2 / group_points_2_3DV) ----
+ * The kNN + radius rule of a second level runs on the level-1 centroid coordinates through facl_group (idx + centred xyz).
+ * facl_gather_rows moves the features: out[r][col_off + c] = feat[m][idx[r]][c] for the rows r = (m, s2, k) of cloud m
+ * (feat (M,S1,C) rows of stride ldf; out rows of stride ldo); with xyz (rows,3) also out[r][0..2] = xyz[r] (col_off = 3:
+ * the reference's concatenated (3+C)-channel rows).  facl_scatter_rows is its transpose (gradient of the gather):
+ * dfeat[m][s][c] = sum_{r: idx[r] = s} drows[r][col_off + c], rows added in index order (deterministic, no atomics). */
+int facl_gather_rows(const float* feat, int ldf, int M, int S1, int C, const int32_t* idx, int rows_per_cloud,
+                     const float* xyz, float* out, int ldo, int col_off, void* stream);
+int facl_scatter_rows(const float* drows, int ldd, int col_off, int M, int S1, int C, const int32_t* idx,
+                      int rows_per_cloud, float* dfeat, void* stream);
 
 /* ---- contrastive losses on a similarity matrix (utils_my.py:53-116) ----------------------------
  * sim (R,J) = anchors @ keys^T, R = nA*B rows (row i*B+n: clip n), J = G*Bk columns (column j belongs to

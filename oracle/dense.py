@@ -1,0 +1,133 @@
+"""Oracle for the dense configuration (BASELINE.json configs[4]: N=4096, T=32, 3-level set abstraction).
+
+TEST INFRASTRUCTURE (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this).
+
+What the reference holds for this configuration:
+  * the second-level groupers ``group_points_2`` (utils_my.py:332-356) and ``group_points_2_3DV`` (:358-381) on
+    channel-first features (B, 3+C, S1): centroids = the first S2 columns, kNN over the S1 columns on xyz, neighbours
+    farther than the radius replaced by the centroid's own column, ALL 3+C channels gathered, xyz centred.  Restated
+    below in NumPy and PINNED by tests/golden/level2.npz (outputs of the reference functions, tools/make_goldens.py);
+  * the channel widths of a second level, ``nstates_plus_2 = [128, 128, 256]`` (cn3d_model_conbag.py:16), which no model
+    of the reference uses.
+No model of the reference consumes a second level, so the 3-level ENCODER below is a build-side composition (SURVEY
+section 8d, "C5: extension without reference oracle"): PARITY UNPINNED for the composition -- each of its layers is the
+same 1x1 conv + BatchNorm2d + ReLU / MaxPool2d construction as cn3d_model_conbag.py:43-77, and the product is checked
+against this restatement only.
+
+  level 1  group_points_3DV_2048 (utils_my.py:7-42)   N -> S1 centroids, K1 neighbours, net3DV_1 D->64->64->256, max_K
+  level 2  group_points_2                              S1 -> S2 centroids, K2 neighbours on cat(centre1, feat1) (3+256),
+                                                       net3DV_2 259->128->128->256, max_K
+  level 3  net3DV_3 259->256->512->1024 on cat(centre2, feat2), max over S2 (my_max_pool) and over gost*S2 (gobaol_max_pool),
+           netR_FC twice, normalize, mapping   (cn3d_model_conbag.py:61-88, :218-232 with level-2 inputs)
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import encoder as E
+from . import grouping as OG
+
+CONV2 = [128, 128, 256]          # nstates_plus_2, cn3d_model_conbag.py:16
+
+
+def group_points_2(points_cf, S2, K, r2):
+    """points_cf (B, 3+C, S1) float32 -> (inputs_level2 (B, 3+C, S2, K), center (B, 3, S2, 1)), utils_my.py:332-356.
+    dist^2 = (dx*dx + dy*dy) + dz*dz in fp32 (``sum(2)`` of a 3-wide axis); K smallest kept (order unspecified in the
+    reference: ascending index here, lower index on ties); kept neighbours with dist^2 > r2 (strict) -> centroid column."""
+    pts = np.ascontiguousarray(points_cf, dtype=np.float32)
+    B, C3, S1 = pts.shape
+    rows = np.ascontiguousarray(pts.transpose(0, 2, 1))                 # (B, S1, 3+C): the row-major twin
+    idx, _ = OG.knn_radius_indices(rows[:, :, :3], S2, K, r2)           # same kNN + radius rule as level 1, xyz only
+    flat = idx.reshape(B, S2 * K).astype(np.int64)
+    g = np.take_along_axis(rows, flat[:, :, None], axis=1).reshape(B, S2, K, C3).copy()
+    cen = rows[:, :S2, :3].copy()
+    g[..., :3] = g[..., :3] - cen[:, :, None, :]
+    return np.ascontiguousarray(g.transpose(0, 3, 1, 2)), np.ascontiguousarray(cen.transpose(0, 2, 1))[..., None]
+
+
+def group_points_2_3DV(points_cf, S2):
+    """utils_my.py:358-381: K = 32 and r^2 = 0.11 literals (:361-362)."""
+    return group_points_2(points_cf, S2, 32, 0.11)
+
+
+def dense_state_shapes(D):
+    """Ordered (key, shape) list: the live model's 52 keys + net3DV_2.{0,1,3,4,6,7}.* between level 1 and level 3."""
+    from .weights import state_dict_shapes
+    out = []
+    for k, shp in state_dict_shapes(D):
+        if k.startswith("net3DV_3.0.") and not any(kk.startswith("net3DV_2.") for kk, _ in out):
+            cin = 3 + 256
+            for li, cout in zip((0, 3, 6), CONV2):
+                out += [(f"net3DV_2.{li}.weight", (cout, cin, 1, 1)), (f"net3DV_2.{li}.bias", (cout,))]
+                b = li + 1
+                out += [(f"net3DV_2.{b}.weight", (cout,)), (f"net3DV_2.{b}.bias", (cout,)),
+                        (f"net3DV_2.{b}.running_mean", (cout,)), (f"net3DV_2.{b}.running_var", (cout,)),
+                        (f"net3DV_2.{b}.num_batches_tracked", ())]
+                cin = cout
+        out.append((k, shp))
+    return out
+
+
+def dense_formula_state_dict(D, seed=0):
+    """Closed-form parameters for the dense model (the live model's formula weights + hash weights for net3DV_2)."""
+    from .weights import _hash_uniform, formula_state_dict
+    base = formula_state_dict(D, seed=seed)
+    sd = {}
+    for n, (key, shape) in enumerate(dense_state_shapes(D)):
+        if key in base:
+            sd[key] = base[key]
+            continue
+        cnt = int(np.prod(shape)) if shape else 1
+        hk = 7_000_003 * (n + 1) + seed
+        if key.endswith("num_batches_tracked"):
+            v = np.array(3, dtype=np.int64)
+        elif key.endswith("running_mean"):
+            v = (0.1 * _hash_uniform(cnt, hk)).astype(np.float32)
+        elif key.endswith("running_var"):
+            v = (1.0 + 0.5 * _hash_uniform(cnt, hk)).astype(np.float32)
+        elif len(shape) == 1 and key.split(".")[1] in ("1", "4", "7") and key.endswith("weight"):
+            v = (1.0 + 0.6 * _hash_uniform(cnt, hk)).astype(np.float32)
+        elif len(shape) == 1 and key.split(".")[1] in ("1", "4", "7"):
+            v = (0.2 * _hash_uniform(cnt, hk)).astype(np.float32)
+        elif key.endswith("bias"):
+            v = (0.1 * _hash_uniform(cnt, hk)).astype(np.float32)
+        else:
+            v = (_hash_uniform(cnt, hk) / np.sqrt(int(np.prod(shape[1:])))).astype(np.float32)
+        sd[key] = v.reshape(shape)
+    return sd
+
+
+def dense_encoder_forward(sd, points, gost, S1, K1, S2, K2, r1, r2, training=True):
+    """points (M, N, D) view-major float tensor -> (x (M,512), code, x_nor, x_global (B,512)).  ``sd`` carries
+    parameters and BN buffers (updated in place in training mode, netR_FC.1 twice)."""
+    dt = points.dtype
+    pts = points.detach().cpu().numpy().astype(np.float32)
+    M = pts.shape[0]
+    _, xt, yt = OG.group_points(pts, S1, K1, r1)                                   # (M,S1,K1,D), (M,S1,3)
+    h = torch.from_numpy(xt).permute(0, 3, 1, 2).to(dt)                            # (M,D,S1,K1)
+    for li in (0, 3, 6):
+        h = E._conv_bn_relu(sd, "net3DV_1", li, h, training)
+    feat1 = F.max_pool2d(h, (1, K1), stride=1).squeeze(-1)                         # (M,256,S1)
+    cen1 = torch.from_numpy(yt).to(dt).permute(0, 2, 1)                            # (M,3,S1)
+    l2_in = torch.cat((cen1, feat1), 1)                                            # (M,259,S1): group_points_2's input
+    # level-2 grouping on the xyz rows (indices from fp32 coordinates: integer work is exact in any feature dtype)
+    idx, _ = OG.knn_radius_indices(yt, S2, K2, r2)
+    idx_t = torch.from_numpy(idx.astype(np.int64)).reshape(M, 1, S2 * K2).expand(M, l2_in.shape[1], S2 * K2)
+    g = l2_in.gather(2, idx_t).view(M, l2_in.shape[1], S2, K2)                     # utils_my.py:349-350
+    cen2 = l2_in[:, 0:3, 0:S2].unsqueeze(3)                                        # :352
+    g = torch.cat((g[:, 0:3] - cen2, g[:, 3:]), 1)                                 # :353
+    h = g
+    for li in (0, 3, 6):
+        h = E._conv_bn_relu(sd, "net3DV_2", li, h, training)
+    feat2 = F.max_pool2d(h, (1, K2), stride=1)                                     # (M,256,S2,1)
+    h = torch.cat((cen2, feat2), 1)                                                # (M,259,S2,1)   cf. :219
+    for li in (0, 3, 6):
+        h = E._conv_bn_relu(sd, "net3DV_3", li, h, training)
+    x_pre = F.max_pool2d(h, (S2, 1), stride=1).squeeze(-1).squeeze(-1)             # :222
+    xg = h.reshape(gost, -1, 1024, S2).permute(1, 2, 0, 3).reshape(-1, 1024, gost * S2, 1)
+    xg_pre = F.max_pool2d(xg, (S2 * gost, 1), stride=1).squeeze(-1).squeeze(-1)    # :225-226
+    x = E._fc_head(sd, x_pre, training)
+    x_global = E._fc_head(sd, xg_pre, training)
+    x_nor = F.normalize(x, p=2, dim=1)
+    code = F.linear(x_nor, sd["mapping.weight"])
+    return x, code, x_nor, x_global

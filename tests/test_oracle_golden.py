@@ -193,3 +193,24 @@ def test_formula_state_dict_has_52_keys():
         assert len(shapes) == 52
         n = sum(int(np.prod(s)) for k, s in shapes if not ("running" in k or "num_batches" in k))
         assert n == {4: 2358144, 3: 2358144 - 64}[D]     # SURVEY §2 row 2 [probed] param count
+
+
+def test_level2_groupers_vs_reference_golden():
+    """oracle.dense.group_points_2 / group_points_2_3DV vs the outputs of the reference's second-level groupers
+    (utils_my.py:332-381) stored by tools/make_goldens.py: make_level2 -- gathered channels exact, xyz centring exact,
+    both radius regimes (r^2 = 0.05: most neighbours collapse to the centroid; 0.30: none do)."""
+    from oracle import dense as OD
+    g = load_golden("level2.npz")
+    B, C, S1, S2 = [int(v) for v in g["meta"]]
+    pts = g["points"]
+    for tag, r2 in (("r005", 0.05), ("r030", 0.30)):
+        xt, ct = OD.group_points_2(pts, S2, 64, r2)
+        assert xt.shape == (B, 3 + C, S2, 64) and ct.shape == (B, 3, S2, 1)
+        np.testing.assert_array_equal(canon_groups_np(xt.transpose(0, 2, 3, 1)), g[f"gp2_{tag}"])
+        np.testing.assert_array_equal(ct, g[f"gp2_{tag}_center"])
+    xt, ct = OD.group_points_2_3DV(pts, S2)
+    np.testing.assert_array_equal(canon_groups_np(xt.transpose(0, 2, 3, 1)), g["gp2_3dv"])
+    np.testing.assert_array_equal(ct, g["gp2_3dv_center"])
+    # the collapse really happens in the small-radius regime
+    zero_off = (np.abs(g["gp2_r005"][..., :3]).sum(-1) == 0).mean()
+    assert zero_off > 0.3

@@ -130,7 +130,8 @@ def kernel_models(a, K=64):
                            bytes=M * (a.N * D * 4.0 + S * K * D * 4.0 + S * 12.0)),
         "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "bf16x6",
                              flops=nunits * 2.0 * 64 * 64 * 64, bytes=nunits * (64 * D * 4.0 + y2)),
-        "facl_sa_fwd3": dict(kernel="k_sa_fwd3" if sa_f32 else "k_sa_fwd3_sb", pipe="f32" if sa_f32 else "bf16x6",
+        "facl_sa_fwd3": dict(kernel="k_sa_fwd3_sb<fp16>" if a.config == "dense" else ("k_sa_fwd3" if sa_f32 else "k_sa_fwd3_sb"),
+                             pipe="f16" if a.config == "dense" else ("f32" if sa_f32 else "bf16x6"),
                              flops=nunits * 2.0 * 64 * 64 * 256, bytes=nunits * (y2 + 1024.0 + 256.0)),
         "facl_sa_bwd1": dict(kernel="k_sa_bwd1", pipe="f32", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
                              bytes=nunits * (2.0 * y2 + 1024 + 256)),

@@ -38,6 +38,7 @@ SIGNATURES = {
     "facl_sa_l1tab": [c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_fwd3_f16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_stats": [c_p, c_l, c_i, c_p, c_p, c_p],
     "facl_rows_bn_relu": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],

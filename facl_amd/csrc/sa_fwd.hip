@@ -471,6 +471,15 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
 // 16kk + 4h + j for j < 4, 16kk + 8 + 4h + (j-4) else; W3's B fragments use the same map).  Per unit and wave:
 // 64 values/lane split into 3 bf16 planes (96 VGPRs), 96 ds_read_b128 of pre-split sgn*W3 fragments, 384 MFMAs.
 // Roofline: MFMA bf16 (2.5 PFLOP/s dense); 6 * 2*64*64*256 executed FLOP per unit.
+// NP = 3: exact 3-way bf16 split (6 products per multiply-add); NP = 1: fp16-input variant of the dense configuration --
+// a2 and W3 rounded to fp16, ONE v_mfma_f32_32x32x16_f16 product, fp32 accumulation (64 MFMAs per unit: HBM-bound).
+typedef _Float16 f16x2q __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16q(float x0, float x1) {
+    const f32x2v v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2q));
+}
+template <int NP>
 __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2f, int nunits,
                                                     const float* __restrict__ sc2, const float* __restrict__ sh2,
                                                     const float* __restrict__ W3, const float* __restrict__ b3,
@@ -490,10 +499,17 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
         const float s = sgn3[c3];
         unsigned hi[4], mi[4], lo[4];
-        split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
-        split_pair(w0.z * s, w0.w * s, hi[1], mi[1], lo[1]);
-        split_pair(w1.x * s, w1.y * s, hi[2], mi[2], lo[2]);
-        split_pair(w1.z * s, w1.w * s, hi[3], mi[3], lo[3]);
+        if (NP == 3) {
+            split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
+            split_pair(w0.z * s, w0.w * s, hi[1], mi[1], lo[1]);
+            split_pair(w1.x * s, w1.y * s, hi[2], mi[2], lo[2]);
+            split_pair(w1.z * s, w1.w * s, hi[3], mi[3], lo[3]);
+        } else {
+            hi[0] = pk_f16q(w0.x * s, w0.y * s); hi[1] = pk_f16q(w0.z * s, w0.w * s);
+            hi[2] = pk_f16q(w1.x * s, w1.y * s); hi[3] = pk_f16q(w1.z * s, w1.w * s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mi[j] = lo[j] = 0u;
+        }
         uint4* d = w3p + ((ct3 * 4 + kk) * 3) * 64 + ln;
         d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
@@ -530,8 +546,14 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                 for (int t = 0; t < 2; ++t) {
                     const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
                     const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
-                    split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
-                    split_pair(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1], lo[2 * t + 1]);
+                    if (NP == 3) {
+                        split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
+                        split_pair(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1], lo[2 * t + 1]);
+                    } else {
+                        hi[2 * t] = pk_f16q(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f));
+                        hi[2 * t + 1] = pk_f16q(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f));
+                        mi[2 * t] = mi[2 * t + 1] = lo[2 * t] = lo[2 * t + 1] = 0u;
+                    }
                 }
                 ap[ct][kk][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
                 ap[ct][kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
@@ -550,10 +572,16 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                 bf16x8 bfr[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, w3p[((ct3 * 4 + kk) * 3 + p) * 64 + lane]);
+                if (NP == 3) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    acc0 = MFMA_BF16(ap[0][kk][PA[t]], bfr[PB[t]], acc0);
-                    acc1 = MFMA_BF16(ap[1][kk][PA[t]], bfr[PB[t]], acc1);
+                    for (int t = 0; t < 6; ++t) {
+                        acc0 = MFMA_BF16(ap[0][kk][PA[t]], bfr[PB[t]], acc0);
+                        acc1 = MFMA_BF16(ap[1][kk][PA[t]], bfr[PB[t]], acc1);
+                    }
+                } else {
+                    const f16x8q wb = __builtin_bit_cast(f16x8q, bfr[0]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, ap[0][kk][0]), wb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, ap[1][kk][0]), wb, acc1, 0, 0, 0);
                 }
             }
             float s = 0.f, sq = 0.f, best = acc0[0];
@@ -650,34 +678,50 @@ extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* 
     return facl_reduce_rows(part, grid * 4, 128, sums2, st);
 }
 
-extern "C" int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
-                            const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
-                            double* sums3, void* ws, void* stream) {
+static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
+                     const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
+                     double* sums3, void* ws, void* stream, int prec) {
     if (!y2f || !scale2 || !shift2 || !W3 || !b3 || !sgn3 || !ymax || !arg || (sums3 && !ws)) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 7) / 8 : SA_GRID);
     // FACL_SA_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one
-    static const int use_f32 = getenv("FACL_SA_F32") ? atoi(getenv("FACL_SA_F32")) : 0;
+    static const int env_f32 = getenv("FACL_SA_F32") ? atoi(getenv("FACL_SA_F32")) : 0;
+    const int use_f32 = env_f32 && prec == 0;
     const size_t lds = use_f32 ? (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2)
                                : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 256 * sizeof(double2);
-    const void* fn = use_f32 ? (const void*)k_sa_fwd3 : (const void*)k_sa_fwd3_sb;
-    static bool attr_done = false;
-    if (!attr_done) {
+    const void* fn = use_f32 ? (const void*)k_sa_fwd3 : prec == 1 ? (const void*)k_sa_fwd3_sb<1> : (const void*)k_sa_fwd3_sb<3>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[prec == 1]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[prec == 1] = true;
     }
     double* part = sums3 ? (double*)ws : nullptr;
     if (use_f32)
         hipLaunchKernelGGL(k_sa_fwd3, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3, ymax,
                            arg, part);
+    else if (prec == 1)
+        hipLaunchKernelGGL((k_sa_fwd3_sb<1>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+                           ymax, arg, part);
     else
-        hipLaunchKernelGGL(k_sa_fwd3_sb, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+        hipLaunchKernelGGL((k_sa_fwd3_sb<3>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
                            ymax, arg, part);
     int rc = facl_launch_status();
     if (rc || !sums3) return rc;
     return facl_reduce_rows(part, grid * 8, 512, sums3, st);
+}
+
+extern "C" int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
+                            const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
+                            double* sums3, void* ws, void* stream) {
+    return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 0);
+}
+// fp16-input twin (dense configuration): a2 and W3 rounded to fp16, one MFMA product per multiply-add, fp32 accumulation
+extern "C" int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
+                                const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
+                                double* sums3, void* ws, void* stream) {
+    return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 1);
 }
 
 extern "C" int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,

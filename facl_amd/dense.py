@@ -15,7 +15,8 @@ What the reference holds for it: the second-level groupers ``group_points_2`` / 
                  normalize, mapping -- exactly cn3d_model_conbag.py:61-88,:218-232 with level-2 inputs.
     Level 1 runs on the fused set-abstraction kernels (facl_amd.sa_mlp), levels 2-3 on the row GEMMs of
     facl_amd.tail with the grouped rows as GEMM rows (the max over the K2 = 64 neighbours is the GEMM's fused segment
-    max); ``precision="f16"`` switches the level-2/3 GEMMs to fp16-input MFMA with fp32 accumulation;
+    max); ``precision="f16"`` switches the level-1 64->256 layer and the level-2/3 GEMMs to fp16-input MFMA with fp32
+    accumulation;
   * ``DenseStep`` (grouping -> forward -> global + circle loss -> backward -> optimizer) and the bench hook.
 """
 import numpy as np
@@ -143,7 +144,8 @@ class PointNet_Plus_dense(nn.Module):
                   n[6].weight, n[6].bias, n[7].weight, n[7].bias]
         buffers = {"rm1": n[1].running_mean, "rv1": n[1].running_var, "rm2": n[4].running_mean,
                    "rv2": n[4].running_var, "rm3": n[7].running_mean, "rv3": n[7].running_var}
-        feat1 = sa_mlp.SAMLPFunction.apply(x_rows, dict(training=training, buffers=buffers, reduce_fn=red, K=K1), *params)
+        feat1 = sa_mlp.SAMLPFunction.apply(x_rows, dict(training=training, buffers=buffers, reduce_fn=red, K=K1, precision=self.precision),
+                                         *params)
         if training:
             for i in (1, 4, 7):
                 n[i].count_batch()
@@ -216,6 +218,6 @@ def make_bench_step(a, dev, rank, world):
     batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]
     workload = (f"dense: motion stream, B={a.B}/GPU T={a.T} N={a.N} D={a.D}, 3-level set abstraction (S1={net.S1} K1={net.K1}, "
                 f"S2={net.S2} K2={net.K2}), global+circle loss, backward, Adam")
-    note = ("level 1 as in the headline config (fp32 results on the bf16 MFMA); level-2/3 point-MLP GEMMs with fp16 inputs "
-            "on v_mfma_f32_32x32x16_f16, fp32 accumulation, fp32 storage")
+    note = ("point-MLP contractions with fp16 inputs on v_mfma_f32_32x32x16_f16 (level-1 64->256 layer, level-2/3 GEMMs, their "
+            "dgrad/wgrad), fp32 accumulation and storage; level-1 first layers and level-1 backward fp32-grade")
     return step, step, batches, "eager", workload, "f16", note

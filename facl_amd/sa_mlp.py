@@ -65,7 +65,7 @@ def _running_update(bnc, rm, rv, n_true):
     rv.mul_(1 - BN_MOMENTUM).add_(unb, alpha=BN_MOMENTUM)
 
 
-def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=64):
+def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=64, precision="f32"):
     """x_rows (P,D) contiguous fp32, P = groups*K rows.  ``p``: dict with W1,b1,g1,be1,rm1,rv1, ...3.
     Returns (pooled (groups,256), ctx) where ctx carries what the backward needs.
     ``reduce_fn(t)`` (optional) all-reduces an fp64 tensor in place (SyncBN).
@@ -145,7 +145,8 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     arg = torch.empty((nunits, 256), dtype=torch.uint8, device=dev)
     sums3 = torch.empty((256, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd3"):
-        _lib.check(lib.facl_sa_fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
+        fwd3 = lib.facl_sa_fwd3_f16 if precision == "f16" else lib.facl_sa_fwd3     # dense configuration: fp16-input 64->256 layer
+        _lib.check(fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
                                     _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
                                     _lib.ptr(ws), st), "facl_sa_fwd3")
     if training:
@@ -262,7 +263,8 @@ class SAMLPFunction(torch.autograd.Function):
     def forward(ctx, x_rows, state, *params):
         p = dict(zip(_PARAM_ORDER, [t.detach().contiguous() for t in params]))
         p.update(state["buffers"])
-        pooled, c = sa_mlp_forward(x_rows, p, state["training"], state.get("reduce_fn"), K=state.get("K", UNIT))
+        pooled, c = sa_mlp_forward(x_rows, p, state["training"], state.get("reduce_fn"), K=state.get("K", UNIT),
+                                   precision=state.get("precision", "f32"))
         ctx.c, ctx.p, ctx.x_rows, ctx.reduce_fn = c, p, x_rows, state.get("reduce_fn")
         ctx.training = state["training"]
         return pooled

@@ -59,6 +59,8 @@ def build_parser(default_branch):
     p.add_argument('--group_radius', type=float, default=None,
                    help='NEW: r^2 of the grouper (default: the reference literals 0.06 at N=512, 0.16 otherwise)')
     p.add_argument('--log_file', type=str, default='', help='NEW: log path (reference: ../ntu/ntu60_new2/30_0425.log)')
+    p.add_argument('--swa_if', type=int, default=0, help='NEW: 1 = add 0.6 * the SwAV term (literal swa_if = 0 at :238)')
+    p.add_argument('--cld_if', type=int, default=0, help='NEW: 1 = add the CLD k-means term (literal cld_if = 0 at :319)')
     p.add_argument('--fps_reorder', type=int, default=0,
                    help='NEW: 1 = FPS-reorder every view on the GPU before grouping (cn3D_data_set.py:665-672; the '
                         'reference assumes FPS-ordered clouds but its live loader never calls it)')
@@ -101,8 +103,11 @@ def appearance_batch(B, G, N, D, device, generator=None):
 class ContrastiveStep:
     """One training iteration = the loop body of cn3d_train_motion_GL.py:224-335."""
 
-    def __init__(self, netR, optimizer, opt, num_crop, group_radius=None, fps_reorder=False):
+    def __init__(self, netR, optimizer, opt, num_crop, group_radius=None, fps_reorder=False, swa_if=0, cld_if=0):
         self.netR, self.optimizer, self.opt, self.G = netR, optimizer, opt, num_crop
+        self.swa_if, self.cld_if = int(swa_if), int(cld_if)
+        self.swav_state = None
+        self.epoch = 0
         self.r2 = group_radius
         self.fps_reorder = fps_reorder
         self.rank = torch.distributed.get_rank() if fdist.is_distributed() else 0
@@ -124,6 +129,7 @@ class ContrastiveStep:
             np.random.shuffle(order)                                               # :297-298
         if not torch.is_tensor(order):
             order = torch.as_tensor(np.asarray(order), dtype=torch.long).to(out_points.device)
+        self.epoch = epoch
         return self.run(out_points, order)
 
     def run(self, out_points, order):
@@ -145,7 +151,16 @@ class ContrastiveStep:
         # global (:265-287) + circle (:290-316) losses: similarity GEMMs + one HIP kernel each (csrc/loss.hip)
         loss_c, loss_circle = contrastive_losses_stacked(G, netR._stacked, order, x_keys=None if x_keys is x else x_keys,
                                                          clip_offset=off)
-        loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0)
+        loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0 ...)
+        if self.swa_if:                                                            # ... unless switched on: :239-263
+            from . import swav_cld
+            if self.swav_state is None:
+                self.swav_state = swav_cld.SwavState(B, G, x_nor.shape[1])
+            self.swav_state.maybe_create(self.epoch, x.device)
+            loss = loss + 0.6 * swav_cld.swav_loss(code, x_nor, netR.mapping.weight, self.swav_state)
+        if self.cld_if:                                                            # :319-326
+            from . import swav_cld
+            loss = loss + swav_cld.cld_loss(x_nor, B, G)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if self.grad_sync is not None:
@@ -225,7 +240,7 @@ def run(default_branch, ckpt_pattern, args=None):
     netR.bn_reduce_fn = fdist.make_bn_reduce_fn()
     # cn3d_train_motion_GL.py:180; fused=True is the same update as one multi-tensor kernel instead of seven
     optimizer = torch.optim.Adam(netR.parameters(), lr=opt.learning_rate, betas=(0.5, 0.999), eps=1e-06, fused=True)
-    step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius, bool(opt.fps_reorder))
+    step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius, bool(opt.fps_reorder), opt.swa_if, opt.cld_if)
     gen = torch.Generator(device=device)
     gen.manual_seed(1000 + rank)
 

@@ -267,6 +267,15 @@ int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J,
 int facl_normalize_map(const float* x, int64_t M, int C, const float* Wm, int K, float* x_nor, float* code,
                        void* stream);
 
+/* ---- optional loss terms of the training loop (switched off in the shipped loop) ----------------------
+ * facl_sinkhorn: distributed_sinkhorn + shoot_infs (cn3d_model_conbag.py:391-425).  Q (R,C) = exp(scores)^T, R prototypes
+ * x C samples; `iters` row/column scalings; out (C,R).  scratch: R*C + R floats.
+ * facl_kmeans: KMeans (cn3d_train_motion_GL.py:54-70): `iters` Lloyd iterations from the first K rows of x (N,D);
+ * labels (N) = final assignment (first minimum on ties), cent (K,D) = final means, counts (K) (an empty cluster: 1). */
+int facl_sinkhorn(const float* Q, int R, int C, int iters, float* scratch, float* out, void* stream);
+int facl_kmeans(const float* x, int N, int D, int K, int iters, int32_t* labels, float* cent, int32_t* counts,
+                void* stream);
+
 /* ---- view construction of a batch of clips (replaces the NumPy pipeline of
  * training_code/cn3D_data_set.py:285-350 get_data_train + :654-663 + :708-713 + :734-749 + :767-778 and the
  * float64->float32 / permute head of cn3d_train_motion_GL.py:225-228) ----------------------------

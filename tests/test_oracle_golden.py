@@ -214,3 +214,16 @@ def test_level2_groupers_vs_reference_golden():
     # the collapse really happens in the small-radius regime
     zero_off = (np.abs(g["gp2_r005"][..., :3]).sum(-1) == 0).mean()
     assert zero_off > 0.3
+
+
+def test_sinkhorn_oracle_vs_reference_golden():
+    """oracle.swav_cld.distributed_sinkhorn (+ shoot_infs) vs the reference's outputs (cn3d_model_conbag.py:391-425,
+    tests/golden/swav.npz); the overflow case reproduces the reference's all-NaN result."""
+    from oracle import swav_cld as O
+    g = load_golden("swav.npz")
+    for tag in ("plain", "queue", "inf"):
+        out = O.distributed_sinkhorn(torch.from_numpy(g[f"{tag}_in"]), 3).numpy()
+        assert np.array_equal(np.isnan(out), np.isnan(g[f"{tag}_out"])), tag
+        if not np.isnan(g[f"{tag}_out"]).all():
+            np.testing.assert_allclose(out, g[f"{tag}_out"], rtol=1e-6, atol=0)
+    assert int(g["inf_ninf"]) > 0 and np.isnan(g["inf_out"]).all()

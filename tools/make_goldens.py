@@ -248,6 +248,22 @@ def make_level2():
     print("level2.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_swav():
+    """cn3d_model_conbag.py:391-425 distributed_sinkhorn / shoot_infs on SwAV-style score matrices exp(code / 0.03)^T:
+    one ordinary, one whose exp overflows to +inf in a few entries (the shoot_infs branch), one with a queue-sized batch."""
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    for tag, (K, n, scale) in (("plain", (64, 32, 0.5)), ("inf", (64, 48, 4.0)), ("queue", (64, 32 * 9, 0.5))):
+        code = torch.randn(n, K, generator=g) * scale
+        po = torch.exp(code / 0.03).t().contiguous()
+        out[f"{tag}_in"] = po.numpy().copy()
+        out[f"{tag}_ninf"] = np.int32(torch.isinf(po).sum().item())
+        out[f"{tag}_out"] = R_model.distributed_sinkhorn(po.clone(), 3).numpy()
+    assert out["inf_ninf"] > 0 and out["plain_ninf"] == 0 and out["queue_ninf"] == 0
+    np.savez_compressed(os.path.join(OUT, "swav.npz"), **out)
+    print("swav.npz", {k: np.shape(v) for k, v in out.items()})
+
+
 def make_fc():
     """linear_classify/fc_model.py:12-25 Final_FC: seeded construction (fingerprints of the N(0, 0.01) weights),
     forward on synthetic features, CrossEntropy loss and its gradients."""
@@ -287,6 +303,7 @@ def main():
     torch.set_num_threads(8)
     make_init()
     make_level2()
+    make_swav()
     make_fc()
     make_fps()
     make_tiny()

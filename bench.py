@@ -280,7 +280,8 @@ def main():
         net = PointNet_Plus(opt, gost=a.T).to(dev).train()
         net.bn_reduce_fn = fdist.make_bn_reduce_fn()
         use_graph = bool(a.graph) and world == 1
-        optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, capturable=use_graph, fused=True)
+        from facl_amd.optim import FusedAdam
+        optim = FusedAdam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)     # cn3d_train_motion_GL.py:180, one launch
         step = ContrastiveStep(net, optim, opt, a.T, fps_reorder=bool(a.fps))
         eager_step = step
         gen = torch.Generator(device=dev)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "facl_scatter_rows": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "facl_sinkhorn": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "facl_kmeans": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "facl_adam_prep": [c_p, c_p, c_f, c_f, c_p, c_p],
+    "facl_adam_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p],
     "facl_ws_bytes": [],
     "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],
     "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],

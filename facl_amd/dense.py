@@ -211,7 +211,8 @@ def make_bench_step(a, dev, rank, world):
     opt = SimpleNamespace(INPUT_FEATURE_NUM=a.D)
     net = PointNet_Plus_dense(opt, gost=a.T, precision="f16").to(dev).train()
     net.bn_reduce_fn = fdist.make_bn_reduce_fn()
-    optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, fused=True)
+    from .optim import FusedAdam
+    optim = FusedAdam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
     step = DenseStep(net, optim, a.T)
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)

@@ -172,7 +172,8 @@ class ContrastiveStep:
 class GraphedStep:
     """The whole training iteration (grouping -> forward -> losses -> backward -> Adam) captured once into a HIP
     graph and replayed: ~250 kernel launches per step collapse into one graph launch, so the step is no longer bound
-    by host launch latency.  Single-GPU only (collectives stay eager); needs Adam(capturable=True)."""
+    by host launch latency.  Single-GPU only (collectives stay eager); the optimizer must keep its step counter on the device
+    (facl_amd.optim.FusedAdam, or torch.optim.Adam(capturable=True))."""
 
     def __init__(self, step, example_points, G):
         self.step, self.G = step, G
@@ -238,8 +239,9 @@ def run(default_branch, ckpt_pattern, args=None):
     num_crop = opt.num_crop
     netR = MODELL.PointNet_Plus(opt, gost=num_crop).to(device)
     netR.bn_reduce_fn = fdist.make_bn_reduce_fn()
-    # cn3d_train_motion_GL.py:180; fused=True is the same update as one multi-tensor kernel instead of seven
-    optimizer = torch.optim.Adam(netR.parameters(), lr=opt.learning_rate, betas=(0.5, 0.999), eps=1e-06, fused=True)
+    # cn3d_train_motion_GL.py:180: the same update as torch.optim.Adam, all tensors in one HIP launch (facl_amd/optim.py)
+    from .optim import FusedAdam
+    optimizer = FusedAdam(netR.parameters(), lr=opt.learning_rate, betas=(0.5, 0.999), eps=1e-06)
     step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius, bool(opt.fps_reorder), opt.swa_if, opt.cld_if)
     gen = torch.Generator(device=device)
     gen.manual_seed(1000 + rank)

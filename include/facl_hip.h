@@ -267,6 +267,16 @@ int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J,
 int facl_normalize_map(const float* x, int64_t M, int C, const float* Wm, int K, float* x_nor, float* code,
                        void* stream);
 
+/* ---- optimizer step (cn3d_train_motion_GL.py:180,:332: Adam, betas (0.5, 0.999), eps 1e-6, no weight decay) ------------
+ * facl_adam_prep: step[0] += 1 (device float), consts = (lr[0] / (1 - b1^t), 1 / sqrt(1 - b2^t)) -- lr and the step
+ * counter live on the device so that a captured HIP graph advances them by itself.
+ * facl_adam_apply: ALL parameter tensors in one launch.  p / g / m / v are HOST arrays of nt <= 64 device pointers
+ * (parameter, gradient, exp_avg, exp_avg_sq), n their element counts; the pointers travel by value in the kernel
+ * arguments. */
+int facl_adam_prep(const float* lr, float* step, float b1, float b2, float* consts, void* stream);
+int facl_adam_apply(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const int* n,
+                    const float* consts, float b1, float b2, float eps, void* stream);
+
 /* ---- optional loss terms of the training loop (switched off in the shipped loop) ----------------------
  * facl_sinkhorn: distributed_sinkhorn + shoot_infs (cn3d_model_conbag.py:391-425).  Q (R,C) = exp(scores)^T, R prototypes
  * x C samples; `iters` row/column scalings; out (C,R).  scratch: R*C + R floats.

@@ -118,3 +118,30 @@ def test_contrastive_pair_on_stacked_embeddings_vs_closed_form_fp64(G, B, C, wor
     g = st.grad.double()
     assert float((g[:G * B] - gr[1]).norm() / gr[1].norm()) < 2e-5
     assert float((g[G * B:] - gr[0]).norm() / gr[0].norm()) < 2e-5
+
+
+def test_fused_adam_equals_torch_adam():
+    """facl_amd.optim.FusedAdam (one launch over all tensors, device-resident step / lr) vs torch.optim.Adam with the
+    reference's hyper-parameters (cn3d_train_motion_GL.py:180): 6 steps on tensors of ragged sizes, a parameter without a
+    gradient, a learning-rate change in between."""
+    from facl_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(1024, 1024), (64, 3, 1, 1), (5,), (2049,), (512, 1024), (7, 11)]
+    pa = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedAdam(pa, lr=3e-4, betas=(0.5, 0.999), eps=1e-6)
+    ob = torch.optim.Adam(pb, lr=3e-4, betas=(0.5, 0.999), eps=1e-6)
+    for it in range(6):
+        if it == 3:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 3e-4 * 0.7
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 2:
+                a.grad = b.grad = None                       # like mapping.weight: no gradient, no update
+                continue
+            g = torch.randn_like(a) * (10.0 ** (i - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max())
+    sd = oa.state_dict()
+    assert int(sd["state"][0]["step"]) == 6 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}

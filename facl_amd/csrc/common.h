@@ -11,6 +11,10 @@ static inline int facl_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// "sign of gamma" arguments (facl_sa_fwd3, facl_gemm_fwd_segmax): callers may pass the BatchNorm weight itself -- the
+// kernels only use its sign, with sign(0) = +1 (a +-1 array, the round-1 convention, maps onto itself)
+__device__ __forceinline__ float sgn_of(float g) { return g < 0.f ? -1.f : 1.f; }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // lanes strictly below this lane, as a 64-bit mask

@@ -135,7 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
         float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
         if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
         float s = 0.f, sq = 0.f;
-        const float sg = (g.smax && jin) ? g.sgn[j] : 1.f;
+        const float sg = (g.smax && jin) ? sgn_of(g.sgn[j]) : 1.f;
         float best = 0.f;
         int bp = 0;
 #pragma unroll

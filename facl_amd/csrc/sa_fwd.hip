@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
         const int ln = i & 63, r4 = (i >> 6) & 3, rt = (i >> 8) & 1, ct3 = i >> 9;
         const int c3 = 32 * ct3 + (ln & 31);
         float4 w = *reinterpret_cast<const float4*>(W3 + c3 * 64 + 32 * rt + 8 * r4 + 4 * (ln >> 5));
-        const float s = sgn3[c3];
+        const float s = sgn_of(sgn3[c3]);
         w.x *= s; w.y *= s; w.z *= s; w.w *= s;
         w3f[i] = w;
     }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
         sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
         sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
     }
-    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn3[threadIdx.x];
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn_of(sgn3[threadIdx.x]);
     __syncthreads();
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
             const double s = st.x + __shfl_xor(st.x, 32, 64);
             const double sq = st.y + __shfl_xor(st.y, 32, 64);
             if (h == 0) {
-                part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = s * (double)sgn3[32 * ct3 + q];   // statistics of y3, not of sgn3*y3
+                part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = s * (double)sgn_of(sgn3[32 * ct3 + q]);   // statistics of y3, not of sgn3*y3
                 part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = sq;
             }
         }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         const int c3 = 32 * ct3 + (ln & 31);
         const float* wrow = W3 + c3 * 64 + 16 * kk + 4 * (ln >> 5);
         float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
-        const float s = sgn3[c3];
+        const float s = sgn_of(sgn3[c3]);
         unsigned hi[4], mi[4], lo[4];
         if (NP == 3) {
             split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
         sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
     }
-    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn3[threadIdx.x];
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn_of(sgn3[threadIdx.x]);
     __syncthreads();
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
 #pragma unroll
         for (int ct3 = 0; ct3 < 8; ++ct3) {
             const double2 st = stat[ct3 * 32 + q];
-            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x * (double)sgn3[32 * ct3 + q];   // statistics of y3, not of sgn3*y3
+            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x * (double)sgn_of(sgn3[32 * ct3 + q]);   // statistics of y3, not of sgn3*y3
             part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = st.y;
         }
     }

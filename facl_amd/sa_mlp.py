@@ -140,7 +140,7 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
             _running_update(bnc2, p["rm2"], p["rv2"], n_true)
     else:
         bnc2 = _bn_eval(64, p["g2"], p["be2"], p["rm2"], p["rv2"])
-    sgn3 = torch.where(p["g3"] < 0, *_plus_minus_one(dev))           # sign(gamma3) with sign(0) = +1
+    sgn3 = p["g3"]                                                    # the kernels take sign(gamma3) themselves (sign(0) = +1)
     ymax = torch.empty((nunits, 256), dtype=torch.float32, device=dev)
     arg = torch.empty((nunits, 256), dtype=torch.uint8, device=dev)
     sums3 = torch.empty((256, 2), **f64) if training else None

@@ -208,7 +208,7 @@ class _LinearBNSegmax(torch.autograd.Function):
         if S == 64 and R % 64 == 0:
             # max over the 64 centroid rows of each cloud inside the GEMM epilogue (sign(gamma) is known before the
             # statistics are; BN + ReLU are monotone per channel): y is not re-read by a pooling pass
-            sgn = torch.where(gamma.detach() < 0, *_plus_minus_one(h.device))
+            sgn = gamma.detach()                              # the kernel takes sign(gamma) itself (sign(0) = +1)
             y = torch.empty((R, C), dtype=torch.float32, device=h.device)
             sums = torch.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
             ymax = torch.empty((M, C), dtype=torch.float32, device=h.device)

@@ -107,6 +107,8 @@ int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* l1tab, cons
 int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
                  const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
                  double* sums3, void* ws, void* stream);
+/* (sgn3 / sgn arguments of facl_sa_fwd3 and facl_gemm_fwd_segmax: only the SIGN of each entry is used, sign(0) = +1, so the
+ * BatchNorm weight itself can be passed.) */
 /* fp16-input twin of facl_sa_fwd3 (dense configuration): a2 and W3 rounded to fp16, one v_mfma_f32_32x32x16_f16 product
  * per multiply-add, fp32 accumulation; same outputs. */
 int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,

@@ -77,7 +77,11 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) cnt += ((key[j] & sel) == prefix) ? 1 : 0;
-            const int total = wave_sum_i32(cnt);                // candidates whose `bit` is 0
+            // wave total of the per-lane counts (0..NPL) as ballots of their bits, popcounted on the scalar unit (the
+            // shuffle reduction was 6 dependent ds_bpermute round trips per radix round)
+            int total = 0;                                      // candidates whose `bit` is 0
+#pragma unroll
+            for (int b = 0; (1 << b) <= NPL; ++b) total += __popcll(__ballot((cnt >> b) & 1)) << b;
             if (total < remaining) { prefix |= (1u << bit); remaining -= total; cand -= total; }
             else cand = total;
             hi = sel;                                           // `bit` is resolved now
@@ -119,6 +123,11 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         // in index order (all of them when the loop exited early; exact-tie rule otherwise)
 
         const size_t grp = (size_t)m * S + c;
+        // Emission in two steps: the kept (index, key) pairs are compacted in ascending index order into a per-wave LDS
+        // slot (ballot / prefix-popcount positions; ~K/NPL lanes are active per pass), then ALL K neighbours are gathered,
+        // centred and stored by K lanes at once -- K/64 full-width store passes per output instead of NPL passes of a
+        // few lanes each.
+        uint32_t* eslot = reinterpret_cast<uint32_t*>(lds) + 4 * N + 64 * CKEYS * wave;      // 256 words per wave
         int base = 0, eq_taken = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
@@ -132,19 +141,34 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             const unsigned long long tm = __ballot(take);
             if (take) {
                 const int pos = base + __popcll(tm & lt);
-                const int id = (__uint_as_float(key[j]) > r2) ? c : i;      // strict >, utils_my.py:272
-                const size_t o = grp * K + pos;
-                if (idx_out) idx_out[o] = id;
-                if (xt_out) {
-                    const float gx = __fsub_rn(xs[id], cx), gy = __fsub_rn(ys[id], cy), gz = __fsub_rn(zs[id], cz);
-                    if (D == 4) {
-                        *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
-                    } else {
-                        xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz;
+                if (K <= 128) { eslot[pos] = (uint32_t)i; eslot[128 + pos] = key[j]; }
+                else {                                           // K > 128 (no slot room): direct form
+                    const int id = (__uint_as_float(key[j]) > r2) ? c : i;
+                    const size_t o = grp * K + pos;
+                    if (idx_out) idx_out[o] = id;
+                    if (xt_out) {
+                        const float gx = __fsub_rn(xs[id], cx), gy = __fsub_rn(ys[id], cy), gz = __fsub_rn(zs[id], cz);
+                        if (D == 4) *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
+                        else { xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz; }
                     }
                 }
             }
             base += __popcll(tm);
+        }
+        if (K <= 128) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+            for (int pos = lane; pos < K; pos += 64) {
+                const int i = (int)eslot[pos];
+                const int id = (__uint_as_float(eslot[128 + pos]) > r2) ? c : i;      // strict >, utils_my.py:272
+                const size_t o = grp * K + pos;
+                if (idx_out) idx_out[o] = id;
+                if (xt_out) {
+                    const float gx = __fsub_rn(xs[id], cx), gy = __fsub_rn(ys[id], cy), gz = __fsub_rn(zs[id], cz);
+                    if (D == 4) *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
+                    else { xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz; }
+                }
+            }
+            asm volatile("" ::: "memory");                      // the slot is rewritten by the next centroid
         }
         if (yt_out && lane < 3) yt_out[grp * 3 + lane] = (lane == 0) ? cx : (lane == 1) ? cy : cz;
     }
@@ -154,7 +178,7 @@ template <int D, int NPL>
 int launch_group(const float* points, int M, int N, int S, int K, float r2, int32_t* idx, float* xt, float* yt,
                  int clipB, hipStream_t st) {
     dim3 grid((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M);
-    const size_t lds = (size_t)N * 4 * sizeof(float) + 4 * 64 * CKEYS * sizeof(uint32_t);   // cloud (SoA) + one key slot per wave
+    const size_t lds = (size_t)N * 4 * sizeof(float) + 4 * 64 * CKEYS * sizeof(uint32_t);   // cloud (SoA) + one key / emission slot per wave
     hipLaunchKernelGGL((k_group<D, NPL>), grid, dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
     return facl_launch_status();
 }

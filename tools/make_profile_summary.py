@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Assemble profiles/rNN_bench_summary.md from the files a GPU run left under gpurun_out/ (bench lines of the four
+commands, prof_rNN kernel stats + summary).  usage: make_profile_summary.py r02"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    go, pr = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+    names = ["bench_line", "bench_appearance", "bench_dense", "bench_2rank_gloo_rehearsal"]
+    for n in names:
+        shutil.copy(os.path.join(go, f"{tag}_{n}.json"), os.path.join(pr, f"{tag}_{n}.json"))
+    shutil.copy(os.path.join(go, f"prof_{tag}", "r_kernel_stats.csv"), os.path.join(pr, f"{tag}_default_cmd_kernel_stats.csv"))
+    L = {n: json.load(open(os.path.join(pr, f"{tag}_{n}.json"))) for n in names}
+    d = L["bench_line"]
+    summ = open(os.path.join(go, f"prof_{tag}_summary.txt")).read()
+    tbl = ("| kernel | ms/launch (in-step HIP events) | bound | achieved | peak | frac | hbm_frac | PMC traffic / algorithmic bytes |\n"
+           "|---|---|---|---|---|---|---|---|\n")
+    for r in ([d["roofline"]] + d["roofline_more"])[:16]:
+        tr = ("%.2f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "-"
+        tbl += "| `%s` | %.4f | %s | %.1f %s | %.0f | %.3f | %.3f | %s |\n" % (
+            r["kernel"], r["ms_per_launch"], r["bound"], r["achieved"], r["unit"], r["peak"], r["frac"], r["hbm_frac"], tr)
+    open(os.path.join(pr, f"{tag}_bench_summary.md"), "w").write(f'''# Round {int(tag[1:])}: bench lines and rocprofv3 --kernel-trace --stats of the driver's command `python3 bench.py`
+
+MI355X, B=32 T=24 N=2048 D=3.  One profiled run = 1 graph-capture step + 3 graph warm-up steps + 5 warm-up + 20 timed steps
+(HIP-graph replay) + 8 eager steps for the in-step kernel timing of the roofline section + the cpu_baseline leg (CPU only).
+Command (on the GPU box, from /tmp with TMPDIR=/tmp):
+`rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_{tag} -o r -- python3 bench.py`
+Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-step figures below divide by 34 steps).
+
+## bench.py lines of this build, un-profiled, same box (`profiles/{tag}_bench_*.json`)
+
+| command | ms/step | clips/s | file |
+|---|---|---|---|
+| `python bench.py` (BASELINE configs[1], headline) | {d["ms_per_step"]} | {d["value"]} | `{tag}_bench_line.json` (cpu_baseline {d["cpu_baseline"]["value"]} clips/s on {d["cpu_baseline"]["cores"]} cores) |
+| `python bench.py --config appearance --D 4` (configs[2]) | {L["bench_appearance"]["ms_per_step"]} | {L["bench_appearance"]["value"]} | `{tag}_bench_appearance.json` |
+| `python bench.py --config dense` (configs[4]: B=8 T=32 N=4096, 3-level SA, fp16-input MFMA) | {L["bench_dense"]["ms_per_step"]} | {L["bench_dense"]["value"]} | `{tag}_bench_dense.json` |
+| `FACL_DIST_BACKEND=gloo python bench.py --gpus 2 --B 16` (2 ranks REHEARSED on one GPU with CPU collectives: launcher, sharded step, SyncBN, all-gather; not a scaling number) | {L["bench_2rank_gloo_rehearsal"]["ms_per_step"]} | {L["bench_2rank_gloo_rehearsal"]["value"]} | `{tag}_bench_2rank_gloo_rehearsal.json` |
+
+## Roofline section of `{tag}_bench_line.json` (every heavy entry, timed inside the step)
+
+{tbl}
+`roofline` = the first row (the longest kernel).  bf16x6 kernels are priced with the bf16 FLOPs they execute (6 per
+algorithmic multiply-add) against 2,500 TFLOP/s; fp32-MFMA kernels (`k_sa_bwd1`, `k_sa_bwd_w3`) with algorithmic FLOPs against
+157.3 TFLOP/s; PMC traffic from `profiles/pmc_traffic.json` (offline `--pmc FETCH_SIZE` / `WRITE_SIZE` passes of this build:
+`{tag}_pmc_hbm_traffic_table.md`).
+
+## rocprofv3 kernel stats of the profiled run
+
+```
+{summ}```
+No `Cijk_*` (rocBLAS / hipBLASLt) kernel is left in the trace.
+''')
+    print("wrote", os.path.join(pr, f"{tag}_bench_summary.md"))
+
+
+if __name__ == "__main__":
+    main()

@@ -27,16 +27,6 @@ class _Workspace:
         return cls._ws[key]
 
 
-_PM1 = {}
-
-
-def _plus_minus_one(dev):
-    key = (dev.type, dev.index)
-    if key not in _PM1:
-        _PM1[key] = (torch.tensor(-1.0, dtype=torch.float32, device=dev), torch.tensor(1.0, dtype=torch.float32, device=dev))
-    return _PM1[key]
-
-
 def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM):
     lib = _lib.load_library()
     bnc = torch.empty((5, C), dtype=torch.float32, device=sums.device)

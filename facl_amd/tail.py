@@ -8,7 +8,7 @@ matching backward passes are the row kernels of csrc/rows.hip.
 import torch
 
 from . import _lib
-from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize, _plus_minus_one
+from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
 
 
 # ---- arithmetic of the dense contractions -------------------------------------------------------------------------------

@@ -67,7 +67,7 @@ LR = 3e-4
 PARAM3_TOL_CPU = 0.15     # measured 7e-4..8e-2: Adam divides by sqrt(v), which amplifies fp32 summation-order noise on small gradients
 
 
-def check_param3(g, params, params0, tol):
+def check_param3(g, params, params0, tol, truth=None):
     """`param3/*` = reference parameters after 3 Adam steps (cn3d_train_motion_GL.py:180,329-333; five tensors kept
     by tools/make_goldens.py).  Adam's normalised update moves every element by <= ~lr per step whatever the gradient's
     size, so the comparison is on the UPDATE (param3 - param0), norm-wise.  net3DV_3.0.bias feeds a train-mode BN: its
@@ -82,8 +82,12 @@ def check_param3(g, params, params0, tol):
         if k in PRE_BN_BIAS or tol is None:
             continue
         err = np.linalg.norm(d_mine - d_ref) / np.linalg.norm(d_ref)
-        print(f"param3 {k:22s} |update| {np.linalg.norm(d_ref):.3e}  rel err of the update {err:.2e}")
-        assert err < tol, (k, err)
+        floor = 0.0
+        if truth is not None:                                   # the golden's own distance to the fp64 three-step update
+            d_true = np.asarray(truth[k], dtype=np.float64).reshape(g[key].shape) - p0
+            floor = np.linalg.norm(d_ref - d_true) / np.linalg.norm(d_true)
+        print(f"param3 {k:22s} |update| {np.linalg.norm(d_ref):.3e}  rel err of the update {err:.2e}  (golden vs fp64 {floor:.2e})")
+        assert err < 2 * floor + tol, (k, err, floor)
 
 
 @pytest.mark.parametrize("tag,D,neg", [("d4", 4, False), ("d3", 3, False), ("d4_neg", 4, True)])
@@ -101,12 +105,37 @@ def test_c1_forward_loss_backward_adam(tag, D, neg):
     yt_t = torch.from_numpy(yt).view(M, 1, S, 3).transpose(1, 3)
     np.testing.assert_array_equal(yt_t.contiguous().numpy(), g["yt"])
 
+    # Truth = the oracle evaluated in fp64.  The golden is the reference's fp32 run on the machine that made it; the
+    # oracle's fp32 run on THIS machine (other core count / oneDNN blocking) rounds differently, and train-mode BN over few
+    # rows plus max-pool near-ties amplify that (golden vs fp64: 4e-5 on d4 up to 1.5e-3 on d3's x_global).  So: the fp64
+    # oracle must sit within fp32 noise of the golden (the PIN), and the fp32 oracle within twice that noise + TOL.
+    def sd_as(dtype):
+        return {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
+                for k, v in formula_state_dict(D, neg_gamma=neg).items()}
+
+    def check(mine32, ref64, gold, name, pin=3e-3):
+        floor = max_rel_rows(gold, ref64)
+        assert floor < pin, (name, floor)                               # fp64 oracle == reference up to its fp32 noise
+        assert max_rel_rows(mine32, gold) < 2 * floor + TOL, name
+
+    xt64, yt64 = xt_t.double(), yt_t.double()
     # eval
     sd = E.clone_state(formula_state_dict(D, neg_gamma=neg))
     with torch.no_grad():
         ev = E.encoder_forward(sd, xt_t, yt_t, G, training=False)
-    for name, t in zip(("x", "code", "x_nor", "x_global"), ev):
-        assert max_rel_rows(t.numpy(), g[f"eval_{name}"]) < TOL, name
+        ev64 = E.encoder_forward(sd_as(torch.float64), xt64, yt64, G, training=False)
+    for name, t, t64 in zip(("x", "code", "x_nor", "x_global"), ev, ev64):
+        check(t.numpy(), t64.numpy(), g[f"eval_{name}"], "eval_" + name)
+
+    # fp64 truth of the first training step (outputs, taps, losses, gradients)
+    sd64 = sd_as(torch.float64)
+    pk = E.param_keys(sd64)
+    for k in pk:
+        sd64[k].requires_grad_(True)
+    out64, inter64 = E.encoder_forward(sd64, xt64, yt64, G, training=True, return_intermediates=True)
+    lc64, lo64 = OL.global_contrast(G, out64[3], out64[0], B), OL.circle_contrast(G, out64[0], B, g["order"])
+    (lc64 + lo64).backward()
+    g64 = {k: sd64[k].grad.numpy() for k in pk if sd64[k].grad is not None}
 
     # 3 training steps
     sd = E.clone_state(formula_state_dict(D, neg_gamma=neg))
@@ -119,15 +148,18 @@ def test_c1_forward_loss_backward_adam(tag, D, neg):
                 sd_probe = E.clone_state(formula_state_dict(D, neg_gamma=neg))
                 _, inter = E.encoder_forward(sd_probe, xt_t, yt_t, G, training=True, return_intermediates=True)
             pooled = inter["pooled"].squeeze(-1).permute(0, 2, 1).numpy()[::4]
-            assert max_rel_rows(pooled, g["train_pooled"]) < TOL
-            assert max_rel_rows(inter["x_pre"].numpy(), g["train_x_pre"]) < TOL
+            pooled64 = inter64["pooled"].detach().squeeze(-1).permute(0, 2, 1).numpy()[::4]
+            check(pooled, pooled64, g["train_pooled"], "pooled")
+            check(inter["x_pre"].numpy(), inter64["x_pre"].detach().numpy(), g["train_x_pre"], "x_pre")
         r = OS.train_step(sd, opt, None, B, G, S, K, 0.06, order, epoch=0, grouped=(xt_t, yt_t))
         losses.append(r["loss"])
         if it == 0:
-            for name, t in zip(("x", "code", "x_nor", "x_global"), r["outputs"]):
-                assert max_rel_rows(t.numpy(), g[f"train_{name}"]) < TOL, name
-            assert abs(r["loss_c"] - float(g["loss_c"])) <= TOL * abs(float(g["loss_c"]))
-            assert abs(r["loss_circle"] - float(g["loss_circle"])) <= TOL * abs(float(g["loss_circle"]))
+            for name, t, t64 in zip(("x", "code", "x_nor", "x_global"), r["outputs"], out64):
+                check(t.numpy(), t64.detach().numpy(), g[f"train_{name}"], name)
+            for mine_l, key, l64 in ((r["loss_c"], "loss_c", float(lc64)), (r["loss_circle"], "loss_circle", float(lo64))):
+                gold = float(g[key])
+                assert abs(gold - l64) <= 1e-3 * abs(l64), key
+                assert abs(mine_l - gold) <= 2 * abs(gold - l64) + TOL * abs(gold), key
             gmax = max(float(g[k]) for k in g if k.startswith("gradnorm/"))
             for k, gr in r["grads"].items():
                 if f"gradnone/{k}" in g:
@@ -143,23 +175,36 @@ def test_c1_forward_loss_backward_adam(tag, D, neg):
                 # atol: 1e-6 of the largest parameter-gradient norm (net3DV_3.7.bias is mathematically
                 # ~0 too: a common shift of x_pre[:,c] is removed by netR_FC's BatchNorm1d).
                 scale = max(gn, 1e-2 * gmax)
-                assert abs(mine - gn) <= GTOL * scale + 1e-5, (k, mine, gn)
+                floor_n = abs(gn - float(np.linalg.norm(g64[k])))        # the golden's own distance to the fp64 truth
+                assert abs(mine - gn) <= 2 * floor_n + GTOL * scale + 1e-5, (k, mine, gn)
                 if f"grad/{k}" in g:
-                    assert np.linalg.norm(gr.numpy() - g[f"grad/{k}"]) <= GTOL * scale + 1e-5, k
+                    floor_v = np.linalg.norm(g[f"grad/{k}"] - g64[k])
+                    assert floor_v <= 6e-2 * scale + 1e-5, (k, floor_v)  # the PIN: fp64 oracle gradient == reference's (fp32 noise: up to 3e-2 on d3)
+                    assert np.linalg.norm(gr.numpy() - g[f"grad/{k}"]) <= 2 * floor_v + GTOL * scale + 1e-5, k
             for k in sd:
                 if "running_" in k:
-                    assert rel_err(sd[k].numpy(), g[f"buf1/{k}"]) < 1e-5, k
+                    floor_b = rel_err(g[f"buf1/{k}"], sd64[k].detach().numpy())      # golden (fp32) vs fp64 truth
+                    assert floor_b < 1e-3, (k, floor_b)
+                    assert rel_err(sd[k].numpy(), g[f"buf1/{k}"]) < 2 * floor_b + 1e-5, k
                 if "num_batches" in k:
                     assert int(sd[k]) == int(g[f"buf1/{k}"]), k
-    np.testing.assert_allclose(losses[0], g["losses3"][0], rtol=TOL)
-    # later steps amplify rounding differences through Adam's normalised update: looser bound
-    np.testing.assert_allclose(losses, g["losses3"], rtol=5e-3)
+    l64 = float(lc64 + lo64)
+    assert abs(losses[0] - g["losses3"][0]) <= 2 * abs(g["losses3"][0] - l64) + TOL * abs(l64)
+    # later steps amplify rounding differences through Adam's normalised update (another CPU's fp32 summation order moves
+    # step 3 by up to 2 %): looser bound
+    np.testing.assert_allclose(losses, g["losses3"], rtol=3e-2)
     for k in sd:
         if "running_" in k:
             # the pre-BN biases random-walk by +-lr per step on their pure-noise gradients (see
             # PRE_BN_BIAS) and running_mean follows them: 1e-4 absolute on values of ~5e-2.
             assert rel_err(sd[k].numpy(), g[f"buf3/{k}"]) < 1e-2, k
-    check_param3(g, {k: v.detach().numpy() for k, v in sd.items()}, formula_state_dict(D, neg_gamma=neg), tol=PARAM3_TOL_CPU)
+    # fp64 truth of the three Adam steps (the fp32 runs -- the reference's and this machine's -- scatter around it)
+    sd64b = sd_as(torch.float64)
+    opt64 = OS.AdamState(sd64b)
+    for it in range(3):
+        OS.train_step(sd64b, opt64, None, B, G, S, K, 0.06, order, epoch=0, grouped=(xt64, yt64))
+    check_param3(g, {k: v.detach().numpy() for k, v in sd.items()}, formula_state_dict(D, neg_gamma=neg), tol=PARAM3_TOL_CPU,
+                 truth={k: v.detach().numpy() for k, v in sd64b.items()})
 
 
 def test_final_fc_golden():

@@ -616,6 +616,137 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
     gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
 }
 
+// ---- small problems: split-K INSIDE the workgroup ---------------------------------------------------------------------------
+// A 64x64-tile GEMM whose grid is one wave of workgroups (the FC head: 800 or 80 rows) is a serial chain of K/32
+// stages per workgroup at ~0.75 us each (split -> LDS -> 12 dependent MFMAs, measured: 4 us + 0.75 us per stage,
+// independent of M and N), i.e. pure latency.  Here KG groups of 4 waves take every KG-th stage of the SAME output tile,
+// each with its own LDS image, and the partial tiles meet in LDS in fixed group order (deterministic); group 0 runs the
+// ordinary epilogue, so bias / statistics / centre term keep working and no slice buffer or second kernel is needed.
+template <int LA, int LB, bool PRO, int NP, int KG>
+__global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
+    constexpr int PL = 64 * SBROW;                                      // one plane of one operand (elements)
+    constexpr int TILE_F = NP * 2 * PL * 2 / 4;                         // both operand images of a group, in floats
+    constexpr int STG = 4 * 32 * 36;                                    // epilogue staging of group 0 (floats)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    unsigned short* const sA = reinterpret_cast<unsigned short*>(smem + grp * TILE_F);
+    unsigned short* const sB = sA + NP * PL;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * 64, j0 = tile.x * 64;
+    const int kbeg = tile.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+    const int nst = (kend - kbeg + BK - 1) / BK, nit = (nst + KG - 1) / KG;
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+    float4 ra4[2], rb4[2];
+    float ra8[8], rb8[8];
+    auto fetch = [&](int k0) {
+        if (k0 + BK <= kend) {                                         // wave-uniform
+            if (LA == KC) load_tile_kc4<1, true>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
+            else load_tile_ic8<1, true>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
+            if (LB == KC) load_tile_kc4<1, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
+            else load_tile_ic8<1, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
+        } else {
+            if (LA == KC) load_tile_kc4<1, false>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
+            else load_tile_ic8<1, false>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
+            if (LB == KC) load_tile_kc4<1, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
+            else load_tile_ic8<1, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
+        }
+    };
+    unsigned pka[12], pkb[12];
+    auto split = [&](int k0) {
+        if (LA == KC) split_tile_kc4<PRO, 1, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
+        else split_tile_ic8<1, NP>(ra8, pka);
+        if (LB == KC) split_tile_kc4<false, 1, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
+        else split_tile_ic8<1, NP>(rb8, pkb);
+    };
+    auto write = [&]() {
+        if (LA == KC) write_tile_kc4<1, NP>(sA, pka, tid);
+        else write_tile_ic8<1, NP>(sA, pka, tid);
+        if (LB == KC) write_tile_kc4<1, NP>(sB, pkb, tid);
+        else write_tile_ic8<1, NP>(sB, pkb, tid);
+    };
+    auto mfma_block = [&](int kk) {
+        bf16x8 af[NP], bf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            af[p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + (32 * wr + q) * SBROW + 16 * kk + 8 * h);
+            bf[p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + (32 * wc + q) * SBROW + 16 * kk + 8 * h);
+        }
+        if constexpr (NP == 1) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]),
+                                                               acc[0][0], 0, 0, 0);
+        } else {
+            constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[0][0] = MFMA_BF16(af[PA[t]], bf[PB[t]], acc[0][0]);
+        }
+    };
+    // stage s of the chunk belongs to group s % KG; a group that runs out of stages re-stages its last one (harmless)
+    // and skips the MFMAs, so that every wave reaches every barrier
+    auto kof = [&](int it) {
+        int s = grp + KG * it;
+        s = s < nst ? s : nst - 1;
+        return kbeg + s * BK;
+    };
+    { const int k0 = kof(0); fetch(k0); split(k0); write(); }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const int kn = kof(it + 1 < nit ? it + 1 : it);
+        fetch(kn);
+        if (grp + KG * it < nst) {                                     // wave-uniform
+            mfma_block(0);
+            mfma_block(1);
+        }
+        split(kn);
+        __syncthreads();
+        write();
+        __syncthreads();
+    }
+    // partial tiles -> LDS (behind group 0's staging area), summed by group 0 in group order
+    float* red = smem + STG;
+    if (grp > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(grp - 1) * 4096 + wave * 1024 + r * 64 + lane] = acc[0][0][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int gg = 0; gg < KG - 1; ++gg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[gg * 4096 + wave * 1024 + r * 64 + lane];
+    gemm_epilogue<1, 1>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+}
+
+constexpr int SBK_KG = 4;
+template <int LA, int LB, bool PRO, int NP>
+int launch_sbk(const GemmArgs& g, int nz, hipStream_t st) {
+    constexpr int TILE_F = NP * 2 * 64 * SBROW * 2 / 4, STG = 4 * 32 * 36;
+    constexpr int F = SBK_KG * TILE_F > STG + (SBK_KG - 1) * 4096 ? SBK_KG * TILE_F : STG + (SBK_KG - 1) * 4096;
+    constexpr int lds = F * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+    hipLaunchKernelGGL((k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>), grid, dim3(256 * SBK_KG), lds, st, g);
+    return facl_launch_status();
+}
+// one wave of 64x64 workgroups and enough stages to share out
+static inline bool sbk_fits(const GemmArgs& g, int nz) {
+    static const int off = getenv("FACL_GEMM_NOSBK") ? atoi(getenv("FACL_GEMM_NOSBK")) : 0;
+    const long long t64 = (long long)((g.NJ + 63) / 64) * ((g.MI + 63) / 64) * nz;
+    return !off && t64 <= 320 && g.kchunk >= 2 * SBK_KG * BK;
+}
+
 // sum over split-K slices: out[e] = sum_z part[z][e], slices added in order (deterministic); four slice loads in flight
 // per thread (a serial chain of nz dependent 16-byte loads per thread ran at a third of the HBM rate)
 __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n4, float* __restrict__ out) {
@@ -649,6 +780,10 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     // FACL_GEMM_F32=1 selects the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split-bf16 ones
     static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
     if (g.prec == 1) {                                                  // fp16-input MFMA, fp32 accumulation
+        if (sbk_fits(g, nz)) {
+            if (rows_per_part) *rows_per_part = 32;
+            return launch_sbk<LA, LB, PRO, 1>(g, nz, st);
+        }
         if (big >= 256) {
             dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
             hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2, 1>), grid, dim3(256), 0, st, g);
@@ -661,6 +796,10 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
         return facl_launch_status();
     }
     if (!use_f32) {
+        if (sbk_fits(g, nz)) {
+            if (rows_per_part) *rows_per_part = 32;
+            return launch_sbk<LA, LB, PRO, 3>(g, nz, st);
+        }
         if (big >= 256) {
             dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
             hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
@@ -749,6 +888,10 @@ static int gemm_wgrad_p(const float* dy, const float* a, int64_t M, int N, int K
     if (!dy || !a || !dW || !slices) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    {   // few rows (the FC head): the workgroup splits the contraction itself and writes dW directly, no slices
+        GemmArgs g1{dy, N, a, lda, dW, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (int)M, nullptr, nullptr, nullptr, prec};
+        if (M <= 8192 && sbk_fits(g1, 1)) return launch<IC, IC, false>(g1, 1, st, nullptr);
+    }
     int kchunk = (int)((M + nz - 1) / nz);
     kchunk = (kchunk + BK - 1) / BK * BK;
     nz = (int)((M + kchunk - 1) / kchunk);

@@ -16,7 +16,8 @@ def _ws():
 
 @pytest.mark.parametrize("M,K,N,pro,ctr", [(256, 64, 128, False, False), (4096, 256, 256, True, True),
                                            (1000, 512, 384, True, False), (32, 1024, 1024, False, False),
-                                           (768, 1024, 512, False, False), (130, 36, 200, True, True)])
+                                           (768, 1024, 512, False, False), (130, 36, 200, True, True),
+                                           (800, 1000, 1024, False, False), (80, 260, 500, True, True)])   # last two: in-workgroup split-K, ragged stages
 def test_gemm_fwd(M, K, N, pro, ctr):
     from facl_amd import _lib
     lib = _lib.load_library()
@@ -45,7 +46,7 @@ def test_gemm_fwd(M, K, N, pro, ctr):
 
 
 @pytest.mark.parametrize("M,N,K,ldw,off", [(4096, 256, 256, 256, 0), (1000, 384, 520, 523 + 1, 4), (32, 512, 1024, 1024, 0),
-                                           (49152 // 8, 1024, 512, 512, 0)])
+                                           (49152 // 8, 1024, 512, 512, 0), (800, 1024, 1024, 1024, 0), (80, 260, 100, 100, 0)])
 def test_gemm_dgrad(M, N, K, ldw, off):
     from facl_amd import _lib
     lib = _lib.load_library()
@@ -60,7 +61,7 @@ def test_gemm_dgrad(M, N, K, ldw, off):
 
 
 @pytest.mark.parametrize("M,N,K,nz", [(4096, 256, 256, 4), (49152 // 4, 512, 256, 12), (1000, 128, 384, 3), (32, 1024, 1024, 1),
-                                      (768, 512, 1024, 2)])
+                                      (768, 512, 1024, 2), (800, 1024, 1024, 4), (300, 256, 192, 2)])
 def test_gemm_wgrad(M, N, K, nz):
     from facl_amd import _lib
     lib = _lib.load_library()

@@ -255,18 +255,19 @@ def main():
     import numpy as np
     import torch
     from facl_amd import dist as fdist
+    ndev = torch.cuda.device_count()
+    # one rank per GPU, bound BEFORE the process group exists (RCCL creates its communicator on the current device);
+    # `% device_count` only matters for the gloo rehearsal of N>1 on a single-GPU box
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     rank, world = fdist.init_from_env()
     if world != a.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
         sys.exit(2)
-    ndev = torch.cuda.device_count()
     if world > ndev and os.environ.get("FACL_DIST_BACKEND") != "gloo":
         print("bench.py: %d ranks but only %d device(s) visible" % (world, ndev), file=sys.stderr)
         sys.exit(2)
-    # one rank per GPU; `% device_count` only matters for the gloo rehearsal of N>1 on a single-GPU box
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     torch.manual_seed(1)                       # opt.manualSeed = 1 (cn3d_train_motion_GL.py:142-144)
     np.random.seed(1)

@@ -221,10 +221,10 @@ def lr_for_epoch(base_lr, epoch, step_size=4, gamma=0.7):
 def run(default_branch, ckpt_pattern, args=None):
     opt = build_parser(default_branch).parse_args(args)
     print(opt)
-    rank, world = fdist.init_from_env()
     local = int(os.environ.get("LOCAL_RANK", opt.main_gpu))
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local)               # before the process group: RCCL binds its communicator to the current device
     device = torch.device("cuda", local)
+    rank, world = fdist.init_from_env()
 
     opt.manualSeed = 1
     random.seed(opt.manualSeed)

@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--T", type=int, default=None, help="views per clip (reference: gost / num_crop; default 24, dense 32)")
     ap.add_argument("--N", type=int, default=None, help="points per view (default 2048, dense 4096)")
     ap.add_argument("--D", type=int, default=3, help="input channels (north_star: 3-ch; checkpoints: 4)")
+    ap.add_argument("--precision", choices=("f32", "x3", "x3b"), default="f32",
+                    help="f32 (default, the headline): fp32-grade bf16x6 contractions; x3: opt-in three-product variant "
+                         "(~1e-5 relative per GEMM); x3b: three products in the BACKWARD GEMMs only (features / loss unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fps", type=int, default=0, help="1: FPS-reorder the views on the GPU inside the timed step")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (single GPU only)")
@@ -130,8 +133,9 @@ def kernel_models(a, K=64):
                            bytes=M * (a.N * D * 4.0 + S * K * D * 4.0 + S * 12.0)),
         "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "bf16x6",
                              flops=nunits * 2.0 * 64 * 64 * 64, bytes=nunits * (64 * D * 4.0 + y2)),
-        "facl_sa_fwd3": dict(kernel="k_sa_fwd3_sb<fp16>" if a.config == "dense" else ("k_sa_fwd3" if sa_f32 else "k_sa_fwd3_sb"),
-                             pipe="f16" if a.config == "dense" else ("f32" if sa_f32 else "bf16x6"),
+        "facl_sa_fwd3": dict(kernel="k_sa_fwd3_sb<fp16>" if a.config == "dense" else ("k_sa_fwd3" if sa_f32 else
+                                    "k_sa_fwd3_sb<x3>" if getattr(a, "precision", "f32") == "x3" else "k_sa_fwd3_sb"),
+                             pipe="f16" if a.config == "dense" else ("f32" if sa_f32 else "bf16x3" if getattr(a, "precision", "f32") == "x3" else "bf16x6"),
                              flops=nunits * 2.0 * 64 * 64 * 256, bytes=nunits * (y2 + 1024.0 + 256.0)),
         "facl_sa_bwd1": dict(kernel="k_sa_bwd1", pipe="f32", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
                              bytes=nunits * (2.0 * y2 + 1024 + 256)),
@@ -148,17 +152,19 @@ def _gemm_model(label):
     parts = label.split()
     kind, dims = parts[0], parts[1]
     m, k, n = (int(v) for v in dims.split("x"))
-    pipe = "f16" if len(parts) > 2 else ("f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6")
+    tag = parts[2] if len(parts) > 2 else ""
+    pipe = "f16" if tag == "f16" else "bf16x3" if tag == "x3" else ("f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6")
     name = {"facl_gemm_fwd": "k_gemm_sb fwd", "facl_gemm_dgrad": "k_gemm_sb dgrad", "facl_gemm_wgrad": "k_gemm_sb wgrad"}[kind]
-    return dict(kernel="%s %s%s" % (name, dims, " (fp16 inputs)" if pipe == "f16" else ""), pipe=pipe, flops=2.0 * m * k * n,
+    return dict(kernel="%s %s%s" % (name, dims, " (fp16 inputs)" if pipe == "f16" else " (bf16x3)" if pipe == "bf16x3" else ""),
+                pipe=pipe, flops=2.0 * m * k * n,
                 bytes=4.0 * (m * k + k * n + m * n))
 
 
 def price(model, ms):
     """One roofline record: both roofs are evaluated, `bound` is the one that allows the LONGER time at its peak."""
     sec = ms * 1e-3
-    ex = model["flops"] * (6.0 if model["pipe"] == "bf16x6" else 1.0)
-    peak_tf = PEAK_MFMA_BF16_TFLOPS if model["pipe"] in ("bf16x6", "f16") else PEAK_MFMA_F32_TFLOPS
+    ex = model["flops"] * {"bf16x6": 6.0, "bf16x3": 3.0}.get(model["pipe"], 1.0)
+    peak_tf = PEAK_MFMA_BF16_TFLOPS if model["pipe"] in ("bf16x6", "bf16x3", "f16") else PEAK_MFMA_F32_TFLOPS
     t_mfma = ex / (peak_tf * 1e12) if model["pipe"] != "valu" else 0.0
     t_hbm = model["bytes"] / (PEAK_HBM_GBPS * 1e9)
     rec = {"kernel": model["kernel"], "ms_per_launch": round(ms, 4)}
@@ -279,6 +285,7 @@ def main():
         from facl_amd.train_common import ContrastiveStep, GraphedStep, synthetic_batch, appearance_batch
         opt = make_opt(a)
         net = PointNet_Plus(opt, gost=a.T).to(dev).train()
+        net.precision = a.precision
         net.bn_reduce_fn = fdist.make_bn_reduce_fn()
         use_graph = bool(a.graph) and world == 1
         from facl_amd.optim import FusedAdam
@@ -303,6 +310,14 @@ def main():
         dtype = "f32"
         dtype_note = ("fp32 storage and accumulation; dense contractions as exact 3-way bf16 splits on the bf16 MFMA "
                       "(6 products per multiply-add, fp32-grade accuracy)")
+        if a.precision == "x3":
+            dtype_note = ("OPT-IN --precision x3 (not the headline): fp32 storage and accumulation; the tail / loss GEMMs and the "
+                          "64->256 set-abstraction layer keep two bf16 pieces per operand, three products per multiply-add "
+                          "(~1e-5 relative; tests/test_gpu_headline.py holds features and loss to the north_star's 1e-4)")
+        elif a.precision == "x3b":
+            dtype_note = ("OPT-IN --precision x3b (not the headline): forward, features and loss exactly as the default; the "
+                          "dgrad / wgrad GEMMs of the tail and the loss use three bf16 products per multiply-add (~1e-5 relative "
+                          "on the gradients)")
 
     def barrier():
         if world > 1:
@@ -332,7 +347,8 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "dtype_note": dtype_note,
-               "config": {"workload": workload, "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode},
+               "config": {"workload": workload, "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode,
+                          "precision": getattr(a, "precision", "f32")},
                "final_loss": final_loss}
         out["roofline"], out["roofline_more"] = rl_main, rl_more
         if world == 1 and not a.no_cpu_baseline and a.config != "dense":

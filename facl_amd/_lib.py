@@ -59,6 +59,11 @@ SIGNATURES = {
     "facl_gemm_fwd_segmax_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_wgrad_f16": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "facl_gemm_fwd_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    "facl_gemm_fwd_segmax_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_dgrad_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
+    "facl_gemm_wgrad_x3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "facl_sa_fwd3_x3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_contrast": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_contrast_pair": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_normalize_map": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p],

@@ -150,11 +150,16 @@ class PointNet_Plus(nn.Module):
         training = self.training
 
         params, buffers = self._sa_args()
-        state = dict(training=training, buffers=buffers, reduce_fn=self.bn_reduce_fn, K=K)
+        prec = getattr(self, "precision", "f32")              # "f32" (default, fp32-grade) or the opt-in "x3" (tail.precision)
+        state = dict(training=training, buffers=buffers, reduce_fn=self.bn_reduce_fn, K=K, precision=prec)
         pooled = sa_mlp.SAMLPFunction.apply(x_rows, state, *params)           # (M*S,256)   net3DV_1 (:218)
         if training:
             for i in (1, 4, 7):
                 self.net3DV_1[i].count_batch()
+        with _tail.precision(prec):
+            return self._tail_forward(pooled, centers, M, S, training)
+
+    def _tail_forward(self, pooled, centers, M, S, training):
 
         # net3DV_3 (:220).  torch.cat((yt, xt), 1) (:219) is never built: the first GEMM takes the centroid xyz as a
         # rank-3 term in its epilogue

@@ -75,6 +75,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
 #define FACL_SB_PA {2, 0, 1, 1, 0, 0}
 #define FACL_SB_PB {0, 2, 1, 0, 1, 0}
+// "bf16x3" (opt-in, precision "x3"): the two leading pieces only, products (hi,mid) (mid,hi) (hi,hi); the dropped terms
+// are <= 3 * 2^-16 |a||b| per product (measured ~1e-5 relative on the GEMM results), half the MFMA work and 2/3 of the LDS
+// traffic of bf16x6.  Never the default: the headline path stays fp32-grade.
+#define FACL_SB3_PA {0, 1, 0}
+#define FACL_SB3_PB {1, 0, 0}
 
 __device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
     const f32x2v v = {x0, x1};

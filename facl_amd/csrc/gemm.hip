@@ -448,7 +448,8 @@ __device__ __forceinline__ void load_tile_ic8(const float* __restrict__ P, int l
 // Staging is two-phase so that the conversion overlaps the MFMAs: split_tile_* turns the raw fp32 registers of the
 // NEXT stage into packed bf16 planes (VALU only, scheduled between the MFMAs of the current stage), write_tile_*
 // is the bare LDS store between the two workgroup barriers.  PK = 12T packed registers per operand.
-// NP = 3: exact 3-way bf16 split; NP = 1: one fp16 plane (round to nearest), for the fp16-input MFMA
+// NP = 3: exact 3-way bf16 split; NP = 2: the two leading bf16 pieces ("bf16x3", common.h); NP = 1: one fp16 plane
+// (round to nearest), for the fp16-input MFMA
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned pk_f16(float x0, float x1) {
@@ -461,7 +462,7 @@ __device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned
     for (int i = 0; i < T; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (NP == 3) split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
+            if (NP >= 2) split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
             else pk[12 * i + j] = pk_f16(r[8 * i + 2 * j], r[8 * i + 2 * j + 1]);
         }
 }
@@ -492,7 +493,7 @@ __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigne
             v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
             v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
         }
-        if (NP == 3) {
+        if (NP >= 2) {
             split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
             split_pair(v[2], v[3], pk[6 * i + 1], pk[6 * i + 3], pk[6 * i + 5]);
         } else {
@@ -588,13 +589,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
             return;
         }
         // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-        constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+        constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB, PA3[3] = FACL_SB3_PA, PB3[3] = FACL_SB3_PB;
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < (NP == 3 ? 6 : 3); ++t)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][NP == 3 ? PA[t] : 0], bf[b][NP == 3 ? PB[t] : 0], acc[a][b]);
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][NP == 3 ? PA[t] : PA3[t]], bf[b][NP == 3 ? PB[t] : PB3[t]], acc[a][b]);
     };
     fetch(kbeg);
     split(kbeg);
@@ -682,9 +683,10 @@ __global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]),
                                                                acc[0][0], 0, 0, 0);
         } else {
-            constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+            constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB, PA3[3] = FACL_SB3_PA, PB3[3] = FACL_SB3_PB;
 #pragma unroll
-            for (int t = 0; t < 6; ++t) acc[0][0] = MFMA_BF16(af[PA[t]], bf[PB[t]], acc[0][0]);
+            for (int t = 0; t < (NP == 3 ? 6 : 3); ++t)
+                acc[0][0] = MFMA_BF16(af[NP == 3 ? PA[t] : PA3[t]], bf[NP == 3 ? PB[t] : PB3[t]], acc[0][0]);
         }
     };
     // stage s of the chunk belongs to group s % KG; a group that runs out of stages re-stages its last one (harmless)
@@ -771,6 +773,24 @@ __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n
     }
 }
 
+template <int LA, int LB, bool PRO, int NP>
+int launch_sb_np(const GemmArgs& g, int nz, long long big, hipStream_t st, int* rows_per_part) {
+    if (sbk_fits(g, nz)) {
+        if (rows_per_part) *rows_per_part = 32;
+        return launch_sbk<LA, LB, PRO, NP>(g, nz, st);
+    }
+    if (big >= 256) {
+        dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+        hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2, NP>), grid, dim3(256), 0, st, g);
+        if (rows_per_part) *rows_per_part = 64;
+    } else {
+        dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+        hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1, NP>), grid, dim3(256), 0, st, g);
+        if (rows_per_part) *rows_per_part = 32;
+    }
+    return facl_launch_status();
+}
+
 // tile choice: 128x128 blocks when they already fill the chip, else 64x64 blocks (4x the workgroups) -- the FC head
 // (M = 768 or 32 rows) would otherwise run on 48 or 8 of the 256 CUs
 template <int LA, int LB, bool PRO>
@@ -779,22 +799,8 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     static const int use_dma = getenv("FACL_GEMM_DMA") ? atoi(getenv("FACL_GEMM_DMA")) : 1;
     // FACL_GEMM_F32=1 selects the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split-bf16 ones
     static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
-    if (g.prec == 1) {                                                  // fp16-input MFMA, fp32 accumulation
-        if (sbk_fits(g, nz)) {
-            if (rows_per_part) *rows_per_part = 32;
-            return launch_sbk<LA, LB, PRO, 1>(g, nz, st);
-        }
-        if (big >= 256) {
-            dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
-            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2, 1>), grid, dim3(256), 0, st, g);
-            if (rows_per_part) *rows_per_part = 64;
-        } else {
-            dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
-            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1, 1>), grid, dim3(256), 0, st, g);
-            if (rows_per_part) *rows_per_part = 32;
-        }
-        return facl_launch_status();
-    }
+    if (g.prec == 1) return launch_sb_np<LA, LB, PRO, 1>(g, nz, big, st, rows_per_part);   // fp16-input MFMA, fp32 accumulation
+    if (g.prec == 2) return launch_sb_np<LA, LB, PRO, 2>(g, nz, big, st, rows_per_part);   // bf16x3 (opt-in)
     if (!use_f32) {
         if (sbk_fits(g, nz)) {
             if (rows_per_part) *rows_per_part = 32;
@@ -939,4 +945,23 @@ extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N
 extern "C" int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                                    float* slices, int nz, void* stream) {
     return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 1);
+}
+
+// ---- "bf16x3" twins (opt-in precision "x3": two bf16 pieces per operand, three products; common.h) -------------------------
+extern "C" int facl_gemm_fwd_x3(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                                const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                                int ldwc, float* y, double* sums, void* ws, void* stream) {
+    return gemm_fwd_p(a, M, K, W, ldw, N, bias, pscale, pshift, centers, Wc, ldwc, y, sums, ws, stream, 2);
+}
+extern "C" int facl_gemm_fwd_segmax_x3(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                                       const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                                       void* stream) {
+    return gemm_fwd_segmax_p(a, M, K, W, ldw, N, bias, sgn, y, sums, ymax, arg, ws, stream, 2);
+}
+extern "C" int facl_gemm_dgrad_x3(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da, void* stream) {
+    return gemm_dgrad_p(dy, M, N, W, ldw, K, da, stream, 2);
+}
+extern "C" int facl_gemm_wgrad_x3(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                                  float* slices, int nz, void* stream) {
+    return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 2);
 }

@@ -471,7 +471,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, 
 // 16kk + 4h + j for j < 4, 16kk + 8 + 4h + (j-4) else; W3's B fragments use the same map).  Per unit and wave:
 // 64 values/lane split into 3 bf16 planes (96 VGPRs), 96 ds_read_b128 of pre-split sgn*W3 fragments, 384 MFMAs.
 // Roofline: MFMA bf16 (2.5 PFLOP/s dense); 6 * 2*64*64*256 executed FLOP per unit.
-// NP = 3: exact 3-way bf16 split (6 products per multiply-add); NP = 1: fp16-input variant of the dense configuration --
+// NP = 3: exact 3-way bf16 split (6 products per multiply-add); NP = 2: "bf16x3" (two pieces, three products: opt-in
+// precision "x3", common.h); NP = 1: fp16-input variant of the dense configuration --
 // a2 and W3 rounded to fp16, ONE v_mfma_f32_32x32x16_f16 product, fp32 accumulation (64 MFMAs per unit: HBM-bound).
 typedef _Float16 f16x2q __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
         const float s = sgn_of(sgn3[c3]);
         unsigned hi[4], mi[4], lo[4];
-        if (NP == 3) {
+        if (NP >= 2) {
             split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
             split_pair(w0.z * s, w0.w * s, hi[1], mi[1], lo[1]);
             split_pair(w1.x * s, w1.y * s, hi[2], mi[2], lo[2]);
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                 for (int t = 0; t < 2; ++t) {
                     const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
                     const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
-                    if (NP == 3) {
+                    if (NP >= 2) {
                         split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
                         split_pair(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1], lo[2 * t + 1]);
                     } else {
@@ -577,6 +578,13 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                     for (int t = 0; t < 6; ++t) {
                         acc0 = MFMA_BF16(ap[0][kk][PA[t]], bfr[PB[t]], acc0);
                         acc1 = MFMA_BF16(ap[1][kk][PA[t]], bfr[PB[t]], acc1);
+                    }
+                } else if (NP == 2) {                                       // bf16x3 (opt-in): (hi,mid) (mid,hi) (hi,hi)
+                    constexpr int PA3[3] = FACL_SB3_PA, PB3[3] = FACL_SB3_PB;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        acc0 = MFMA_BF16(ap[0][kk][PA3[t]], bfr[PB3[t]], acc0);
+                        acc1 = MFMA_BF16(ap[1][kk][PA3[t]], bfr[PB3[t]], acc1);
                     }
                 } else {
                     const f16x8q wb = __builtin_bit_cast(f16x8q, bfr[0]);
@@ -690,12 +698,14 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
     const int use_f32 = env_f32 && prec == 0;
     const size_t lds = use_f32 ? (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2)
                                : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 256 * sizeof(double2);
-    const void* fn = use_f32 ? (const void*)k_sa_fwd3 : prec == 1 ? (const void*)k_sa_fwd3_sb<1> : (const void*)k_sa_fwd3_sb<3>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[prec == 1]) {
+    const void* fn = use_f32 ? (const void*)k_sa_fwd3 : prec == 1 ? (const void*)k_sa_fwd3_sb<1>
+                   : prec == 2 ? (const void*)k_sa_fwd3_sb<2> : (const void*)k_sa_fwd3_sb<3>;
+    static bool attr_done[3] = {false, false, false};
+    if (prec < 0 || prec > 2) return FACL_E_CONFIG;
+    if (!attr_done[prec]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done[prec == 1] = true;
+        attr_done[prec] = true;
     }
     double* part = sums3 ? (double*)ws : nullptr;
     if (use_f32)
@@ -703,6 +713,9 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
                            arg, part);
     else if (prec == 1)
         hipLaunchKernelGGL((k_sa_fwd3_sb<1>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+                           ymax, arg, part);
+    else if (prec == 2)
+        hipLaunchKernelGGL((k_sa_fwd3_sb<2>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
                            ymax, arg, part);
     else
         hipLaunchKernelGGL((k_sa_fwd3_sb<3>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
@@ -722,6 +735,13 @@ extern "C" int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* s
                                 const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
                                 double* sums3, void* ws, void* stream) {
     return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 1);
+}
+
+// "bf16x3" twin (opt-in precision "x3")
+extern "C" int facl_sa_fwd3_x3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
+                               const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
+                               double* sums3, void* ws, void* stream) {
+    return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 2);
 }
 
 extern "C" int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,

@@ -135,7 +135,8 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     arg = torch.empty((nunits, 256), dtype=torch.uint8, device=dev)
     sums3 = torch.empty((256, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd3"):
-        fwd3 = lib.facl_sa_fwd3_f16 if precision == "f16" else lib.facl_sa_fwd3     # dense configuration: fp16-input 64->256 layer
+        # dense configuration: fp16-input 64->256 layer; "x3": the opt-in three-product variant (tail.precision)
+        fwd3 = {"f32": lib.facl_sa_fwd3, "f16": lib.facl_sa_fwd3_f16, "x3": lib.facl_sa_fwd3_x3, "x3b": lib.facl_sa_fwd3}[precision]
         _lib.check(fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
                                     _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
                                     _lib.ptr(ws), st), "facl_sa_fwd3")

@@ -13,15 +13,21 @@ from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
 
 # ---- arithmetic of the dense contractions -------------------------------------------------------------------------------
 # "f32": fp32-grade results (exact 3-way bf16 split on the bf16 MFMA, or the fp32 MFMA with FACL_GEMM_F32=1);
-# "f16": fp16-input MFMA with fp32 accumulation (dense configuration).  The precision in force when a layer's FORWARD
-# runs is recorded on its autograd context and used again by its backward GEMMs.
+# "f16": fp16-input MFMA with fp32 accumulation (dense configuration);
+# "x3":  opt-in "bf16x3" -- two bf16 pieces per operand, three products per multiply-add (~1e-5 relative on a GEMM result,
+#        inside the north_star's 1e-4 for features / loss; half the MFMA work).  Never the default.
+# "x3b": "x3" in the BACKWARD GEMMs only (dgrad / wgrad): forward, features and loss are those of "f32" to the bit, the
+#        gradients carry ~1e-5 relative rounding (far below what Adam's update noise of the reference itself is).
+# The precision in force when a layer's FORWARD runs is recorded on its autograd context and used again by its backward GEMMs.
 _PRECISION = ["f32"]
+PRECISIONS = ("f32", "f16", "x3", "x3b")
+_SUFFIX = {"f32": "", "f16": "_f16", "x3": "_x3", "x3b": ""}          # "x3b" only changes what _PrecGuard installs
 
 
 class precision:
     def __init__(self, p):
-        if p not in ("f32", "f16"):
-            raise ValueError("precision must be 'f32' or 'f16'")
+        if p not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
         self.p = p
 
     def __enter__(self):
@@ -41,18 +47,18 @@ class _PrecGuard:
     """Scope guard for backward(): restores the precision when the frame that created it returns (or raises)."""
 
     def __init__(self, p):
-        _PRECISION.append(p)
+        _PRECISION.append("x3" if p == "x3b" else p)
 
     def __del__(self):
         _PRECISION.pop()
 
 
 def _plabel():
-    return " f16" if _PRECISION[-1] == "f16" else ""
+    return {"f32": "", "f16": " f16", "x3": " x3", "x3b": ""}[_PRECISION[-1]]
 
 
 def _fn(lib, name):
-    return getattr(lib, name + "_f16") if _PRECISION[-1] == "f16" else getattr(lib, name)
+    return getattr(lib, name + _SUFFIX[_PRECISION[-1]])
 
 
 def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):

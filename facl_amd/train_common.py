@@ -61,6 +61,9 @@ def build_parser(default_branch):
     p.add_argument('--log_file', type=str, default='', help='NEW: log path (reference: ../ntu/ntu60_new2/30_0425.log)')
     p.add_argument('--swa_if', type=int, default=0, help='NEW: 1 = add 0.6 * the SwAV term (literal swa_if = 0 at :238)')
     p.add_argument('--cld_if', type=int, default=0, help='NEW: 1 = add the CLD k-means term (literal cld_if = 0 at :319)')
+    p.add_argument('--precision', type=str, default='f32', choices=('f32', 'x3b', 'x3'),
+                   help='NEW: arithmetic of the dense contractions (facl_amd.tail.precision): f32 = fp32-grade (default); '
+                        'x3b = three bf16 products in the backward GEMMs only (features / loss unchanged); x3 = everywhere')
     p.add_argument('--fps_reorder', type=int, default=0,
                    help='NEW: 1 = FPS-reorder every view on the GPU before grouping (cn3D_data_set.py:665-672; the '
                         'reference assumes FPS-ordered clouds but its live loader never calls it)')
@@ -149,8 +152,10 @@ class ContrastiveStep:
         x_keys = fdist.all_gather_view_major(x, G)
         off = self.rank * B
         # global (:265-287) + circle (:290-316) losses: similarity GEMMs + one HIP kernel each (csrc/loss.hip)
-        loss_c, loss_circle = contrastive_losses_stacked(G, netR._stacked, order, x_keys=None if x_keys is x else x_keys,
-                                                         clip_offset=off)
+        from .tail import precision as _precision
+        with _precision(getattr(netR, "precision", "f32")):    # the similarity GEMMs follow the model's arithmetic
+            loss_c, loss_circle = contrastive_losses_stacked(G, netR._stacked, order, x_keys=None if x_keys is x else x_keys,
+                                                             clip_offset=off)
         loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0 ...)
         if self.swa_if:                                                            # ... unless switched on: :239-263
             from . import swav_cld
@@ -238,6 +243,7 @@ def run(default_branch, ckpt_pattern, args=None):
 
     num_crop = opt.num_crop
     netR = MODELL.PointNet_Plus(opt, gost=num_crop).to(device)
+    netR.precision = opt.precision
     netR.bn_reduce_fn = fdist.make_bn_reduce_fn()
     # cn3d_train_motion_GL.py:180: the same update as torch.optim.Adam, all tensors in one HIP launch (facl_amd/optim.py)
     from .optim import FusedAdam

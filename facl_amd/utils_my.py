@@ -229,6 +229,7 @@ class _ContrastivePair(torch.autograd.Function):
         J = keys.shape[0]
         Bk = J // G
         ctx.mfma = (J % 4 == 0 and C % 4 == 0)     # the MFMA GEMMs contract over multiples of 4; odd toy shapes: library GEMM
+        ctx.prec = _tail.current_precision()       # the backward GEMMs run in the forward's arithmetic
         sim = _tail.gemm_fwd(stacked, keys, None)[0] if ctx.mfma else stacked @ keys.t()     # ((G+1)B, J)  :71 and :103
         dsim = torch.empty_like(sim)
         out = torch.empty(2, dtype=torch.float64, device=dev)
@@ -242,6 +243,7 @@ class _ContrastivePair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_c, g_o):
         from . import tail as _tail
+        _guard = _tail._PrecGuard(ctx.prec)
         stacked, keys, dsim = ctx.saved_tensors
         # rows [0, G*B) carry the circle loss, rows [G*B, (G+1)*B) the global loss: one scaling launch for both
         lib = _lib.load_library()

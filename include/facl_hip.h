@@ -230,6 +230,22 @@ int facl_gemm_dgrad_f16(const float* dy, int64_t M, int N, const float* W, int l
                         void* stream);
 int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                         float* slices, int nz, void* stream);
+/* "bf16x3" twins (opt-in precision "x3"; never the default): each operand keeps its two leading bf16 pieces and a
+ * multiply-add is three products (hi*mid, mid*hi, hi*hi) instead of six -- relative error of a product <= 3 * 2^-16
+ * (results ~1e-5 of an fp64 GEMM; the north_star's tolerance for features / loss is 1e-4), half the MFMA work. */
+int facl_gemm_fwd_x3(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                     const float* pscale, const float* pshift, const float* centers, const float* Wc, int ldwc,
+                     float* y, double* sums, void* ws, void* stream);
+int facl_gemm_fwd_segmax_x3(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                            const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
+                            void* stream);
+int facl_gemm_dgrad_x3(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
+                       void* stream);
+int facl_gemm_wgrad_x3(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                       float* slices, int nz, void* stream);
+int facl_sa_fwd3_x3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
+                    const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
+                    void* stream);
 
 /* ---- second-level grouping on channel-first features (utils_my.py:332-381 group_points_2 / group_points_2_3DV) ----
  * The kNN + radius rule of a second level runs on the level-1 centroid coordinates through facl_group (idx + centred xyz).

@@ -137,3 +137,33 @@ def test_gemm_fwd_segmax_fused_epilogue():
     # too small for the 128x128-tile kernel: the entry point says so and launches nothing
     assert lib.facl_gemm_fwd_segmax(p(a), 128, K, p(W), K, 256, p(b), p(sgn), p(y), None, p(ymax), p(arg), p(_ws()),
                                     _lib.stream()) == -4
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 256, 512), (800, 1024, 1024), (1000, 104, 200)])
+def test_gemm_x3_twins_within_their_bound(M, K, N):
+    """The opt-in "bf16x3" entries (two bf16 pieces per operand, three products): forward / dgrad / wgrad against fp64.
+    Bound stated in include/facl_hip.h: <= 3 * 2^-16 per product; measured ~1e-5 of the result's scale."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    p, st = _lib.ptr, _lib.stream()
+    y, y6 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    sums = torch.empty(N, 2, dtype=torch.float64, device=DEV)
+    _lib.check(lib.facl_gemm_fwd_x3(p(a), M, K, p(W), K, N, p(b), None, None, None, None, 0, p(y), p(sums), p(_ws()), st), "fwd_x3")
+    _lib.check(lib.facl_gemm_fwd(p(a), M, K, p(W), K, N, p(b), None, None, None, None, 0, p(y6), None, p(_ws()), st), "fwd")
+    ref = a.double() @ W.double().t() + b.double()
+    e3, e6 = rel_err(y.cpu().numpy(), ref.cpu().numpy()), rel_err(y6.cpu().numpy(), ref.cpu().numpy())
+    assert e6 < 2e-6 and e6 < e3 < 5e-5, (e3, e6)                      # really the three-product arithmetic, inside its bound
+    assert rel_err(sums[:, 1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 5e-5
+    da = torch.empty(M, K, device=DEV)
+    _lib.check(lib.facl_gemm_dgrad_x3(p(dy), M, N, p(W), K, K, p(da), st), "dgrad_x3")
+    assert rel_err(da.cpu().numpy(), (dy.double() @ W.double()).cpu().numpy()) < 5e-5
+    nz = 4
+    dW = torch.empty(N, K, device=DEV)
+    sl = torch.empty(nz * N * K, device=DEV)
+    _lib.check(lib.facl_gemm_wgrad_x3(p(dy), p(a), M, N, K, K, p(dW), p(sl), nz, st), "wgrad_x3")
+    assert rel_err(dW.cpu().numpy(), (dy.double().t() @ a.double()).cpu().numpy()) < 5e-5

@@ -63,8 +63,10 @@ def _forward64(x_rows, centers, sd, G, S, K):
     return x, xg, stats, q
 
 
-@pytest.mark.parametrize("stream,D", [("motion", 3), ("appearance", 4)])
-def test_full_step_at_headline_size_vs_torch_fp64(stream, D):
+# prec "x3" / "x3b": the opt-in three-product arithmetic (facl_amd.tail.precision).  "x3b" (backward GEMMs only) must
+# reproduce the default path's features and losses; "x3" is ~1e-5 per GEMM result (losses 4e-6, worst feature row ~1e-4)
+@pytest.mark.parametrize("stream,D,prec", [("motion", 3, "f32"), ("appearance", 4, "f32"), ("motion", 3, "x3"), ("motion", 3, "x3b")])
+def test_full_step_at_headline_size_vs_torch_fp64(stream, D, prec):
     from facl_amd.cn3d_model_conbag import PointNet_Plus
     from facl_amd.train_common import ContrastiveStep, appearance_batch, synthetic_batch
     from facl_amd.utils_my import knn_radius_group
@@ -79,6 +81,8 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D):
     net = PointNet_Plus(opt, gost=G)
     net.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     net = net.to(DEV).train()
+    net.precision = prec
+    stat_tol = 1e-4 if prec == "x3" else 1e-5           # "x3b" changes the backward only
     optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06, fused=True)
     step = ContrastiveStep(net, optim, opt, G)
     order = np.random.RandomState(5).permutation(G)
@@ -101,9 +105,12 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D):
     e_x = max_rel_rows(taps["x"].cpu().numpy(), x64.cpu().numpy())
     e_xg = max_rel_rows(taps["xg"].cpu().numpy(), xg64.cpu().numpy())
     e_lc, e_lo = abs(loss_c.item() - lc64) / abs(lc64), abs(loss_circle.item() - lo64) / abs(lo64)
-    print(f"[{stream}] x {e_x:.2e}  x_global {e_xg:.2e}  loss_c {loss_c.item():.6f} vs {lc64:.6f} ({e_lc:.2e})  "
+    print(f"[{stream} {prec}] x {e_x:.2e}  x_global {e_xg:.2e}  loss_c {loss_c.item():.6f} vs {lc64:.6f} ({e_lc:.2e})  "
           f"loss_circle {loss_circle.item():.6f} vs {lo64:.6f} ({e_lo:.2e})")
-    assert e_x < TOL and e_xg < TOL
+    # "x3" everywhere sits AT the north_star bound on the worst feature row (measured 7e-5 / 9.9e-5): held to 2e-4 here and
+    # documented as such; the default path and "x3b" are 20x inside it
+    ftol = 2e-4 if prec == "x3" else TOL
+    assert e_x < ftol and e_xg < ftol
     assert e_lc < TOL and e_lo < TOL
     assert abs(loss.item() - (lc64 + lo64)) < TOL * abs(lc64 + lo64)
     # ---- running statistics after the step (momentum 0.1; netR_FC.1 is updated twice: view rows, then clip rows)
@@ -112,13 +119,13 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D):
         mean, uvar = stats[key]
         rm = 0.9 * q[f"{key}.running_mean"] + 0.1 * mean
         rv = 0.9 * q[f"{key}.running_var"] + 0.1 * uvar
-        assert rel_err(st[f"{key}.running_mean"].cpu().numpy(), rm.cpu().numpy()) < 1e-5, key
-        assert rel_err(st[f"{key}.running_var"].cpu().numpy(), rv.cpu().numpy()) < 1e-5, key
+        assert rel_err(st[f"{key}.running_mean"].cpu().numpy(), rm.cpu().numpy()) < stat_tol, key
+        assert rel_err(st[f"{key}.running_var"].cpu().numpy(), rv.cpu().numpy()) < stat_tol, key
         assert int(st[f"{key}.num_batches_tracked"]) == int(sd[f"{key}.num_batches_tracked"]) + 1
     rm = 0.9 * (0.9 * q["netR_FC.1.running_mean"] + 0.1 * stats["fc_a"][0]) + 0.1 * stats["fc_b"][0]
     rv = 0.9 * (0.9 * q["netR_FC.1.running_var"] + 0.1 * stats["fc_a"][1]) + 0.1 * stats["fc_b"][1]
-    assert rel_err(st["netR_FC.1.running_mean"].cpu().numpy(), rm.cpu().numpy()) < 1e-5
-    assert rel_err(st["netR_FC.1.running_var"].cpu().numpy(), rv.cpu().numpy()) < 1e-5
+    assert rel_err(st["netR_FC.1.running_mean"].cpu().numpy(), rm.cpu().numpy()) < stat_tol
+    assert rel_err(st["netR_FC.1.running_var"].cpu().numpy(), rv.cpu().numpy()) < stat_tol
     assert int(st["netR_FC.1.num_batches_tracked"]) == int(sd["netR_FC.1.num_batches_tracked"]) + 2
     # ---- the Adam step happened: every parameter that has a gradient moved by <= ~lr, the pre-BN biases did not move
     for k, p in net.named_parameters():

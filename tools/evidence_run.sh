@@ -10,6 +10,8 @@ mkdir -p "$O"
 timeout -k 10 300 python bench.py | tail -n 1 > "$O/${TAG}_bench_line.json"
 timeout -k 10 300 python bench.py --config appearance --D 4 --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_appearance.json"
 timeout -k 10 300 python bench.py --config dense --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_dense.json"
+timeout -k 10 300 python bench.py --precision x3b --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_optin_x3b.json"
+timeout -k 10 300 python bench.py --precision x3 --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_optin_x3.json"
 FACL_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --B 16 --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_2rank_gloo_rehearsal.json"
 cd /tmp
 export TMPDIR=/tmp

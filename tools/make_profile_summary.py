@@ -13,6 +13,8 @@ def main():
     tag = sys.argv[1]
     go, pr = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
     names = ["bench_line", "bench_appearance", "bench_dense", "bench_2rank_gloo_rehearsal"]
+    optin = [n for n in ("bench_optin_x3b", "bench_optin_x3") if os.path.exists(os.path.join(go, f"{tag}_{n}.json"))]
+    names += optin
     for n in names:
         shutil.copy(os.path.join(go, f"{tag}_{n}.json"), os.path.join(pr, f"{tag}_{n}.json"))
     shutil.copy(os.path.join(go, f"prof_{tag}", "r_kernel_stats.csv"), os.path.join(pr, f"{tag}_default_cmd_kernel_stats.csv"))
@@ -25,6 +27,9 @@ def main():
         tr = ("%.2f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "-"
         tbl += "| `%s` | %.4f | %s | %.1f %s | %.0f | %.3f | %.3f | %s |\n" % (
             r["kernel"], r["ms_per_launch"], r["bound"], r["achieved"], r["unit"], r["peak"], r["frac"], r["hbm_frac"], tr)
+    optin_rows = "".join(
+        f'| `python bench.py --precision {n.split("_")[-1]}` (OPT-IN arithmetic, not the headline: DESIGN 3.0) | {L[n]["ms_per_step"]} | '
+        f'{L[n]["value"]} | `{tag}_{n}.json` |\n' for n in optin)
     open(os.path.join(pr, f"{tag}_bench_summary.md"), "w").write(f'''# Round {int(tag[1:])}: bench lines and rocprofv3 --kernel-trace --stats of the driver's command `python3 bench.py`
 
 MI355X, B=32 T=24 N=2048 D=3.  One profiled run = 1 graph-capture step + 3 graph warm-up steps + 5 warm-up + 20 timed steps
@@ -41,7 +46,7 @@ Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-ste
 | `python bench.py --config appearance --D 4` (configs[2]) | {L["bench_appearance"]["ms_per_step"]} | {L["bench_appearance"]["value"]} | `{tag}_bench_appearance.json` |
 | `python bench.py --config dense` (configs[4]: B=8 T=32 N=4096, 3-level SA, fp16-input MFMA) | {L["bench_dense"]["ms_per_step"]} | {L["bench_dense"]["value"]} | `{tag}_bench_dense.json` |
 | `FACL_DIST_BACKEND=gloo python bench.py --gpus 2 --B 16` (2 ranks REHEARSED on one GPU with CPU collectives: launcher, sharded step, SyncBN, all-gather; not a scaling number) | {L["bench_2rank_gloo_rehearsal"]["ms_per_step"]} | {L["bench_2rank_gloo_rehearsal"]["value"]} | `{tag}_bench_2rank_gloo_rehearsal.json` |
-
+{optin_rows}
 ## Roofline section of `{tag}_bench_line.json` (every heavy entry, timed inside the step)
 
 {tbl}

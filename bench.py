@@ -116,6 +116,17 @@ def _pmc_traffic(a, kernel):
     return None, None
 
 
+def _pmc_mfma(a, kernel):
+    """MFMA-pipe utilisation of the launch from OFFLINE PMC passes (profiles/pmc_mfma_util.json, r02_pmc_mfma_util.md)."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma_util.json")))
+        if pm["shape"] == {"B": a.B, "T": a.T, "N": a.N, "D": a.D} and getattr(a, "precision", "f32") == "f32":
+            return pm.get(kernel)
+    except Exception:
+        pass
+    return None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Roofline models of the heavy entry points (DESIGN.md section 3 derives every figure).  A "unit" is one group of 64
 # neighbour positions; nunits = M*S.  pipe "f32": v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s, algorithmic FLOPs);
@@ -207,6 +218,9 @@ def step_rooflines(a, eager_step, batches, nsteps=8):
         r["traffic"], src = _pmc_traffic(a, m["kernel"])
         if src:
             r["traffic_source"] = src
+        mu = _pmc_mfma(a, m["kernel"])
+        if mu:
+            r["mfma_util_pmc"] = mu            # {"busy_frac", "MfmaUtil" (rocprofv3, %), "clock_ghz"}: offline counters, same build
         recs.append(r)
     recs.sort(key=lambda r: -r["ms_per_launch"])
     # sub-20-us launches are glue, not roofline material (kept only when nothing else was measured: toy shapes)

@@ -59,6 +59,63 @@ __global__ __launch_bounds__(64) void k_scatter_rows(const float* __restrict__ d
         for (int s = 0; s < S1; ++s) dfeat[((size_t)m * S1 + s) * C + c] = acc[s * 64 + lane];
 }
 
+// The same sum with the destination range of a cloud cut into `parts` slices: workgroup (part, cloud) owns the destinations
+// [lo, lo + SP), keeps a [SP][C] accumulator in LDS (32 KiB for the dense level 2: 3-4 workgroups per CU instead of ONE
+// single-wave workgroup per CU with the 128 KiB [S1][64] accumulator above), builds the ascending list of ITS rows once
+// (wave 0: ballot compaction of the cloud's idx, 4 bytes per entry in LDS) and then every wave adds its own 64-channel
+// chunks of those rows, 8 row loads in flight, in list order -> deterministic, no atomics; each row is read by exactly one
+// workgroup.  3.3 -> ~0.7 ms for the dense configuration's 2.1 M rows x 256 channels.
+__global__ __launch_bounds__(256) void k_scatter_rows_p(const float* __restrict__ drows, int ldd, int col_off, int C,
+                                                        const int32_t* __restrict__ idx, int rows_per_cloud, int S1, int SP,
+                                                        float* __restrict__ dfeat) {
+    extern __shared__ float acc[];                                       // [SP][C] then the row list
+    unsigned* list = reinterpret_cast<unsigned*>(acc + (size_t)SP * C);
+    __shared__ int nlist;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = blockIdx.y;
+    const int lo = blockIdx.x * SP, hi = lo + SP < S1 ? lo + SP : S1;
+    for (int i = threadIdx.x; i < SP * C; i += 256) acc[i] = 0.f;
+    const int32_t* ix = idx + (size_t)m * rows_per_cloud;
+    if (wave == 0) {
+        int n = 0;
+        for (int r0 = 0; r0 < rows_per_cloud; r0 += 64) {
+            const int r = r0 + lane;
+            const int id = r < rows_per_cloud ? ix[r] : -1;
+            const bool mine = id >= lo && id < hi;
+            const unsigned long long b = __ballot(mine);
+            if (mine) list[n + __popcll(b & lanemask_lt())] = (unsigned)r | ((unsigned)(id - lo) << 20);
+            n += __popcll(b);
+        }
+        if (lane == 0) nlist = n;
+    }
+    __syncthreads();
+    const int n = nlist;
+    const float* src = drows + (size_t)m * rows_per_cloud * ldd + col_off;
+    for (int c0 = 64 * wave; c0 < C; c0 += 256) {                        // this wave's channel chunks
+        const int c = c0 + lane;
+        const bool on = c < C;
+        int e = 0;
+        for (; e + 8 <= n; e += 8) {
+            float v[8];
+            unsigned ent[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ent[j] = list[e + j];
+                v[j] = on ? src[(size_t)(ent[j] & 0xfffffu) * ldd + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (on) acc[(ent[j] >> 20) * C + c] += v[j];
+        }
+        for (; e < n; ++e) {
+            const unsigned ent = list[e];
+            if (on) acc[(ent >> 20) * C + c] += src[(size_t)(ent & 0xfffffu) * ldd + c];
+        }
+    }
+    __syncthreads();
+    float* dst = dfeat + ((size_t)m * S1 + lo) * C;                      // [hi - lo][C] is contiguous
+    for (int i = threadIdx.x; i < (hi - lo) * C; i += 256) dst[i] = acc[i];
+}
+
 }  // namespace
 
 extern "C" int facl_gather_rows(const float* feat, int ldf, int M, int S1, int C, const int32_t* idx, int rows_per_cloud,
@@ -80,8 +137,25 @@ extern "C" int facl_scatter_rows(const float* drows, int ldd, int col_off, int M
                                  int rows_per_cloud, float* dfeat, void* stream) {
     if (!drows || !idx || !dfeat) return FACL_E_NULL;
     if (M < 0 || S1 < 1 || C < 1 || rows_per_cloud < 1 || col_off < 0 || ldd < col_off + C) return FACL_E_SHAPE;
-    if ((size_t)S1 * 64 * sizeof(float) > 160 * 1024 || M > 65535) return FACL_E_SHAPE;
     if (M == 0) return 0;
+    if (M > 65535) return FACL_E_SHAPE;
+    {   // destination slices of <= 32 KiB of accumulator each (several workgroups per CU) + the row list
+        int SP = (int)(32768 / ((size_t)C * sizeof(float)));
+        if (SP > S1) SP = S1;
+        const size_t lds = (size_t)SP * C * sizeof(float) + (size_t)rows_per_cloud * sizeof(unsigned);
+        if (SP >= 1 && SP <= 4096 && rows_per_cloud <= (1 << 20) && lds <= 96 * 1024) {
+            static size_t attr_p = 0;
+            if (lds > attr_p) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_scatter_rows_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+                attr_p = lds;
+            }
+            hipLaunchKernelGGL(k_scatter_rows_p, dim3((S1 + SP - 1) / SP, M), dim3(256), lds, (hipStream_t)stream, drows, ldd,
+                               col_off, C, idx, rows_per_cloud, S1, SP, dfeat);
+            return facl_launch_status();
+        }
+    }
+    if ((size_t)S1 * 64 * sizeof(float) > 160 * 1024) return FACL_E_SHAPE;
     const size_t lds = (size_t)S1 * 64 * sizeof(float);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

@@ -221,4 +221,14 @@ def make_bench_step(a, dev, rank, world):
                 f"S2={net.S2} K2={net.K2}), global+circle loss, backward, Adam")
     note = ("point-MLP contractions with fp16 inputs on v_mfma_f32_32x32x16_f16 (level-1 64->256 layer, level-2/3 GEMMs, their "
             "dgrad/wgrad), fp32 accumulation and storage; level-1 first layers and level-1 backward fp32-grade")
-    return step, step, batches, "eager", workload, "f16", note
+    mode, run_step = "eager", step
+    if world == 1 and getattr(a, "graph", 1):
+        from .train_common import GraphedStep
+        try:
+            run_step = GraphedStep(step, batches[0], a.T)           # the whole iteration replayed as one HIP graph
+            mode = "hipgraph"
+        except Exception as e:                                      # never lose the measurement to a capture problem
+            import sys
+            print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+            net.zero_grad(set_to_none=True)
+    return run_step, step, batches, mode, workload, "f16", note

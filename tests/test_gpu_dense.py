@@ -32,7 +32,7 @@ def test_group_points_2_dropins_vs_reference_golden():
     assert torch.equal(pts, before)                                   # the input is not modified
 
 
-@pytest.mark.parametrize("M,S1,C,S2,K", [(3, 128, 256, 32, 64), (2, 512, 256, 128, 64), (1, 40, 7, 5, 3)])
+@pytest.mark.parametrize("M,S1,C,S2,K", [(3, 128, 256, 32, 64), (2, 512, 256, 128, 64), (1, 40, 7, 5, 3), (2, 96, 320, 7, 9)])
 def test_gather_scatter_rows_vs_torch(M, S1, C, S2, K):
     """facl_gather_rows == torch.gather on the rows; facl_scatter_rows == its autograd transpose (index_add), exactly
     the same sums up to fp32 addition order (the kernel adds a cloud's rows in index order)."""

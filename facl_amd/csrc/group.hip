@@ -68,24 +68,22 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         // Invariant: `cand` keys share the resolved prefix, `remaining` of them belong to the K smallest.
         // Early exit as soon as cand == remaining (all candidates are kept): on continuous data the candidate
         // set shrinks to `remaining` after ~log2(N) mantissa bits, i.e. roughly half of the 31 rounds.
+        // One round = ONE compare per key: with `below` = number of keys under the resolved prefix, the keys under
+        // pivot = prefix | bit number below + (candidates whose bit is 0), so the wave count of (key < pivot) -- a ballot
+        // per register, popcounted on the scalar unit -- decides the bit; no mask / equality test per key.
         uint32_t prefix = 0, hi = 0;
-        int remaining = K, cand = NPL * 64;                     // padding keys (+inf) are ordinary candidates
+        int below = 0, cand = NPL * 64;                         // padding keys (+inf) are ordinary candidates
         int bit = 30;
-        for (; bit >= 0 && cand != remaining && cand > 64 * CKEYS; --bit) {
-            hi = ~((2u << bit) - 1u);                           // bits above `bit`
-            const uint32_t sel = hi | (1u << bit);
-            int cnt = 0;
+        for (; bit >= 0 && cand != K - below && cand > 64 * CKEYS; --bit) {
+            const uint32_t pivot = prefix | (1u << bit);
+            int c = 0;
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) cnt += ((key[j] & sel) == prefix) ? 1 : 0;
-            // wave total of the per-lane counts (0..NPL) as ballots of their bits, popcounted on the scalar unit (the
-            // shuffle reduction was 6 dependent ds_bpermute round trips per radix round)
-            int total = 0;                                      // candidates whose `bit` is 0
-#pragma unroll
-            for (int b = 0; (1 << b) <= NPL; ++b) total += __popcll(__ballot((cnt >> b) & 1)) << b;
-            if (total < remaining) { prefix |= (1u << bit); remaining -= total; cand -= total; }
-            else cand = total;
-            hi = sel;                                           // `bit` is resolved now
+            for (int j = 0; j < NPL; ++j) c += __popcll(__ballot(key[j] < pivot));
+            if (c < K) { prefix = pivot; cand -= c - below; below = c; }   // the K-th smallest is >= pivot: bit = 1
+            else cand = c - below;
+            hi = ~((1u << bit) - 1u);                           // `bit` and everything above it are resolved now
         }
+        int remaining = K - below;
         if (bit >= 0 && cand != remaining) {
             // At most 64*CKEYS candidates are left (the range that holds the K-th smallest halves every round): gather
             // them into CKEYS keys per lane through a small LDS slot and finish the remaining rounds -- typically half
@@ -102,20 +100,18 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
             uint32_t ck[CKEYS];
-            bool valid[CKEYS];
 #pragma unroll
-            for (int i = 0; i < CKEYS; ++i) {
-                valid[i] = lane + 64 * i < cand;
-                ck[i] = valid[i] ? slot[lane + 64 * i] : 0u;
-            }
+            for (int i = 0; i < CKEYS; ++i) ck[i] = lane + 64 * i < cand ? slot[lane + 64 * i] : 0xFFFFFFFFu;   // never < pivot
+            int cbelow = 0;                                     // compacted keys under the prefix (none yet: all are >= it)
             for (; bit >= 0 && cand != remaining; --bit) {
-                const uint32_t sel = hi | (1u << bit);
-                int total = 0;
+                const uint32_t pivot = prefix | (1u << bit);
+                int c = 0;
 #pragma unroll
-                for (int i = 0; i < CKEYS; ++i) total += __popcll(__ballot(valid[i] && (ck[i] & sel) == prefix));
-                if (total < remaining) { prefix |= (1u << bit); remaining -= total; cand -= total; }
-                else cand = total;
-                hi = sel;
+                for (int i = 0; i < CKEYS; ++i) c += __popcll(__ballot(ck[i] < pivot));
+                const int zeros = c - cbelow;                   // candidates whose `bit` is 0
+                if (zeros < remaining) { prefix = pivot; remaining -= zeros; cand -= zeros; cbelow = c; }
+                else cand = zeros;
+                hi = ~((1u << bit) - 1u);
             }
             asm volatile("" ::: "memory");                      // the slot is rewritten by the next centroid
         }

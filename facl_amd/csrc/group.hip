@@ -119,51 +119,64 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         // in index order (all of them when the loop exited early; exact-tie rule otherwise)
 
         const size_t grp = (size_t)m * S + c;
-        // Emission in two steps: the kept (index, key) pairs are compacted in ascending index order into a per-wave LDS
-        // slot (ballot / prefix-popcount positions; ~K/NPL lanes are active per pass), then ALL K neighbours are gathered,
-        // centred and stored by K lanes at once -- K/64 full-width store passes per output instead of NPL passes of a
-        // few lanes each.
+        // Emission in two steps: the kept indices are compacted in ascending order into a per-wave LDS slot (ballot /
+        // prefix-popcount positions; ~K/NPL lanes are active per pass), then ALL K neighbours are gathered, radius-tested
+        // (the distance is recomputed from the coordinates the gather reads anyway: same exact arithmetic), centred and
+        // stored by K lanes at once -- K/64 full-width store passes per output instead of NPL passes of a few lanes each.
         uint32_t* eslot = reinterpret_cast<uint32_t*>(lds) + 4 * N + 64 * CKEYS * wave;      // 256 words per wave
-        int base = 0, eq_taken = 0;
+        // the direct form of one kept neighbour (index i, output slot pos): radius rule, gather, centre, store
+        auto emit = [&](int i, int pos) {
+            const float px = xs[i], py = ys[i], pz = zs[i];
+            const bool outside = dist2_exact(px, py, pz, cx, cy, cz) > r2;              // strict >, utils_my.py:272
+            const int id = outside ? c : i;
+            const size_t o = grp * K + pos;
+            if (idx_out) idx_out[o] = id;
+            if (xt_out) {
+                // the centroid's own centred coordinates are exactly +0 (x - x)
+                const float gx = outside ? 0.f : __fsub_rn(px, cx), gy = outside ? 0.f : __fsub_rn(py, cy);
+                const float gz = outside ? 0.f : __fsub_rn(pz, cz);
+                if (D == 4) *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
+                else { xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz; }
+            }
+        };
+        int base = 0;
+        if (cand == remaining) {
+            // every candidate is kept (the usual exit on continuous data): kept <=> key < prefix + 2^(lowest resolved bit),
+            // ONE compare per key, no tie ranking
+            const uint32_t upper = hi ? prefix + (~hi + 1u) : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int i = j * 64 + lane;
-            const uint32_t kh = key[j] & hi;
-            const bool is_eq = kh == prefix;
-            const unsigned long long eqm = __ballot(is_eq);
-            const int eq_rank = eq_taken + __popcll(eqm & lt);
-            eq_taken += __popcll(eqm);
-            const bool take = (kh < prefix) || (is_eq && eq_rank < remaining);
-            const unsigned long long tm = __ballot(take);
-            if (take) {
-                const int pos = base + __popcll(tm & lt);
-                if (K <= 128) { eslot[pos] = (uint32_t)i; eslot[128 + pos] = key[j]; }
-                else {                                           // K > 128 (no slot room): direct form
-                    const int id = (__uint_as_float(key[j]) > r2) ? c : i;
-                    const size_t o = grp * K + pos;
-                    if (idx_out) idx_out[o] = id;
-                    if (xt_out) {
-                        const float gx = __fsub_rn(xs[id], cx), gy = __fsub_rn(ys[id], cy), gz = __fsub_rn(zs[id], cz);
-                        if (D == 4) *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
-                        else { xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz; }
-                    }
+            for (int j = 0; j < NPL; ++j) {
+                const bool take = key[j] < upper;
+                const unsigned long long tm = __ballot(take);
+                if (take) {
+                    const int pos = base + __popcll(tm & lt);
+                    if (K <= 256) eslot[pos] = (uint32_t)(j * 64 + lane);
+                    else emit(j * 64 + lane, pos);
                 }
+                base += __popcll(tm);
             }
-            base += __popcll(tm);
+        } else {
+            int eq_taken = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const uint32_t kh = key[j] & hi;
+                const bool is_eq = kh == prefix;
+                const unsigned long long eqm = __ballot(is_eq);
+                const int eq_rank = eq_taken + __popcll(eqm & lt);
+                eq_taken += __popcll(eqm);
+                const bool take = (kh < prefix) || (is_eq && eq_rank < remaining);
+                const unsigned long long tm = __ballot(take);
+                if (take) {
+                    const int pos = base + __popcll(tm & lt);
+                    if (K <= 256) eslot[pos] = (uint32_t)(j * 64 + lane);
+                    else emit(j * 64 + lane, pos);
+                }
+                base += __popcll(tm);
+            }
         }
-        if (K <= 128) {
+        if (K <= 256) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
-            for (int pos = lane; pos < K; pos += 64) {
-                const int i = (int)eslot[pos];
-                const int id = (__uint_as_float(eslot[128 + pos]) > r2) ? c : i;      // strict >, utils_my.py:272
-                const size_t o = grp * K + pos;
-                if (idx_out) idx_out[o] = id;
-                if (xt_out) {
-                    const float gx = __fsub_rn(xs[id], cx), gy = __fsub_rn(ys[id], cy), gz = __fsub_rn(zs[id], cz);
-                    if (D == 4) *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
-                    else { xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz; }
-                }
-            }
+            for (int pos = lane; pos < K; pos += 64) emit((int)eslot[pos], pos);
             asm volatile("" ::: "memory");                      // the slot is rewritten by the next centroid
         }
         if (yt_out && lane < 3) yt_out[grp * 3 + lane] = (lane == 0) ? cx : (lane == 1) ? cy : cz;

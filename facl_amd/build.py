@@ -30,8 +30,18 @@ def build_variant(out_path, csrc_dir, verbose=False):
     """Build an experimental library from another source directory (A/B timing in one process)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(glob.glob(os.path.join(csrc_dir, "*.hip")))
-    cmd = [hipcc] + FLAGS + ["-o", out_path] + srcs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    objdir = out_path + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in srcs:                                  # per file, so that EXTRA_FLAGS apply exactly as in build()
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(r.stdout.decode(errors="replace"))
+        objs.append(obj)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path] + objs, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(r.stdout.decode(errors="replace"))
     return out_path

@@ -193,6 +193,95 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
     }
 }
 
+// The same epilogue staged 32 rows (one MFMA row tile) at a time: half the LDS of gemm_epilogue for 128x128 blocks (35 KiB
+// instead of 69 KiB).  Used by the fp16-input instantiation, whose operand images are small (one plane): three workgroups
+// per CU instead of two for GEMMs that are latency-bound (4-8 stages per tile at K = 128 / 256).  Per-column state
+// (statistics, running max) lives in registers across the row-tile passes; sums accumulate in the same order.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_h(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int i0, int j0,
+                                                int wave, int lane, int by, int bz) {
+    const int h = lane >> 5, q = lane & 31, wr = wave >> 1, wc = wave & 1;
+    constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
+    float* Cz = g.C + (size_t)bz * g.MI * g.ldc;
+    float* stg = smem + wave * (32 * SP);
+    float bias[TN], xb0[TN], xb1[TN], xb2[TN], s[TN], sq[TN], sg[TN], best[TN];
+    int bp[TN];
+    bool jin[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + WC * wc + 32 * b + q;
+        jin[b] = j < g.NJ;
+        bias[b] = (g.bias && jin[b]) ? g.bias[j] : 0.f;
+        xb0[b] = xb1[b] = xb2[b] = 0.f;
+        if (g.xa && jin[b]) { xb0[b] = g.xb[(size_t)j * g.ldxb]; xb1[b] = g.xb[(size_t)j * g.ldxb + 1]; xb2[b] = g.xb[(size_t)j * g.ldxb + 2]; }
+        s[b] = sq[b] = 0.f;
+        sg[b] = (g.smax && jin[b]) ? sgn_of(g.sgn[j]) : 1.f;
+        best[b] = 0.f;
+        bp[b] = 0;
+    }
+    const int jw = j0 + WC * wc;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + WC <= g.NJ);
+    constexpr int LPR = WC / 4;                                            // lanes per row (float4 each)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = rowmap(r, h);
+                const int i = i0 + WR * wr + 32 * a + il;
+                float v = acc[a][b][r] + bias[b];
+                if (g.xa && i < g.MI)
+                    v = fmaf(g.xa[(size_t)i * 3], xb0[b], fmaf(g.xa[(size_t)i * 3 + 1], xb1[b], fmaf(g.xa[(size_t)i * 3 + 2], xb2[b], v)));
+                stg[il * SP + 32 * b + q] = v;
+                if (i < g.MI && jin[b]) { s[b] += v; sq[b] = fmaf(v, v, sq[b]); }
+                if (TM == 2 && g.smax) {
+                    const float sv = sg[b] * v;
+                    if ((a == 0 && r == 0) || sv > best[b]) { best[b] = sv; bp[b] = 32 * a + rowmap(r, 0); }
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // same-wave LDS hand-off (lanes swap roles)
+#pragma unroll
+        for (int t = 0; t < 32 * LPR / 64; ++t) {
+            const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
+            const int i = i0 + WR * wr + 32 * a + il;
+            if (i >= g.MI) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
+            if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
+            else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
+            }
+        }
+        asm volatile("" ::: "memory");                                     // the next row tile reuses the staging rows
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + WC * wc + 32 * b + q;
+        if (TM == 2 && g.smax) {                                           // the wave tile's 64 rows = one cloud
+            int p = bp[b] + 4 * h;
+            float bv = best[b];
+            const float ob = __shfl_xor(bv, 32, 64);
+            const int op = __shfl_xor(p, 32, 64);
+            if (ob > bv || (ob == bv && op < p)) { bv = ob; p = op; }      // first max wins (MaxPool2d)
+            if (h == 0 && jin[b]) {
+                const size_t o = (size_t)((i0 + WR * wr) >> 6) * g.NJ + j;
+                g.smax[o] = bv;
+                g.sarg[o] = p;
+            }
+        }
+        if (g.part) {
+            const float st = s[b] + __shfl_xor(s[b], 32, 64), sqt = sq[b] + __shfl_xor(sq[b], 32, 64);
+            if (h == 0 && jin[b]) {
+                double* pr = g.part + ((size_t)(by * 2 + wr) * g.NJ + j) * 2;
+                pr[0] = (double)st; pr[1] = (double)sqt;
+            }
+        }
+    }
+}
+
 template <int LA, int LB, bool PRO, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;
@@ -515,15 +604,17 @@ __device__ __forceinline__ void write_tile_kc4(unsigned short* __restrict__ S, c
 
 
 template <int LA, int LB, bool PRO, int TM, int TN, int NP = 3>
-__global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
+__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int APL = BM * SBROW, BPL = BN * SBROW;                   // one bf16 plane of each operand (elements)
-    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);                  // epilogue staging (floats)
-    constexpr int TILE_F = (3 * (APL + BPL) * 2 + 3) / 4;               // operand images in floats
+    // epilogue staging (floats): the fp16-input instantiation stages one 32-row tile at a time (gemm_epilogue_h) and keeps
+    // only its single operand plane -> 35 KiB of LDS, three workgroups per CU
+    constexpr int STG = NP == 1 ? 4 * 32 * (32 * TN + 4) : 4 * (32 * TM) * (32 * TN + 4);
+    constexpr int TILE_F = ((NP == 1 ? 1 : 3) * (APL + BPL) * 2 + 3) / 4;   // operand images in floats
     constexpr int SMEM = TILE_F > STG ? TILE_F : STG;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     unsigned short* const sA = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* const sB = sA + 3 * APL;
+    unsigned short* const sB = sA + (NP == 1 ? 1 : 3) * APL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const TileId tile = xcd_tile();
@@ -614,7 +705,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
         write();
         __syncthreads();
     }
-    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+    if constexpr (NP == 1) gemm_epilogue_h<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+    else gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
 }
 
 // ---- small problems: split-K INSIDE the workgroup ---------------------------------------------------------------------------

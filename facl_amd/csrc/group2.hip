@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void k_scatter_rows(const float* __restrict__ d
 // [lo, lo + SP), keeps a [SP][C] accumulator in LDS (32 KiB for the dense level 2: 3-4 workgroups per CU instead of ONE
 // single-wave workgroup per CU with the 128 KiB [S1][64] accumulator above), builds the ascending list of ITS rows once
 // (wave 0: ballot compaction of the cloud's idx, 4 bytes per entry in LDS) and then every wave adds its own 64-channel
-// chunks of those rows, 8 row loads in flight, in list order -> deterministic, no atomics; each row is read by exactly one
+// chunks of those rows, 16 row loads in flight, in list order -> deterministic, no atomics; each row is read by exactly one
 // workgroup.  3.3 -> ~0.7 ms for the dense configuration's 2.1 M rows x 256 channels.
 __global__ __launch_bounds__(256) void k_scatter_rows_p(const float* __restrict__ drows, int ldd, int col_off, int C,
                                                         const int32_t* __restrict__ idx, int rows_per_cloud, int S1, int SP,
@@ -94,16 +94,16 @@ __global__ __launch_bounds__(256) void k_scatter_rows_p(const float* __restrict_
         const int c = c0 + lane;
         const bool on = c < C;
         int e = 0;
-        for (; e + 8 <= n; e += 8) {
-            float v[8];
-            unsigned ent[8];
+        for (; e + 16 <= n; e += 16) {                                   // 16 row loads in flight per wave
+            float v[16];
+            unsigned ent[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 16; ++j) {
                 ent[j] = list[e + j];
                 v[j] = on ? src[(size_t)(ent[j] & 0xfffffu) * ldd + c] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 16; ++j)
                 if (on) acc[(ent[j] >> 20) * C + c] += v[j];
         }
         for (; e < n; ++e) {

@@ -128,6 +128,33 @@ def test_group_vs_oracle(dev, M, N, D, S, K, r2):
     np.testing.assert_array_equal(yt.squeeze(-1).permute(0, 2, 1).cpu().numpy(), ryt)
 
 
+def test_group_random_sweep_vs_oracle(dev):
+    """Seeded sweep over shapes the fixed cases do not hit: K in the slot range (<= 256) and above it (direct emission),
+    K not a multiple of 64, N up to 4096, clouds with heavy exact duplicates (the tie-ranking emission path) next to
+    continuous ones (the single-compare path), D = 3 / 4, radii from "everything collapses" to "nothing does"."""
+    from facl_amd import utils_my
+    from oracle import grouping as OG
+    rng = np.random.RandomState(2024)
+    for case in range(14):
+        N = int(rng.choice([96, 130, 512, 777, 1024, 2048, 4096]))
+        K = int(rng.choice([1, 5, 64, 100, 128, 200, 256, 300]))
+        K = min(K, N)
+        S = int(rng.choice([1, 16, 33, 64]))
+        S = min(S, N)
+        D = int(rng.choice([3, 4]))
+        M = int(rng.choice([1, 3]))
+        r2 = float(rng.choice([0.0, 0.01, 0.06, 0.16, 10.0]))
+        pts = (rng.rand(M, N, D) - 0.5).astype(np.float32)
+        if case % 2:                                                    # duplicates: a third of the points are copies
+            src = rng.randint(0, N, size=N // 3)
+            dst = rng.randint(0, N, size=N // 3)
+            pts[:, dst] = pts[:, src]
+        xt, yt, idx = utils_my.knn_radius_group(torch.from_numpy(pts).to(dev), S, K, r2, want_idx=True)
+        ridx, rxt, ryt = OG.group_points(pts, S, K, r2)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx, err_msg=f"case {case}: N={N} K={K} S={S} D={D} r2={r2}")
+        np.testing.assert_array_equal(xt.permute(0, 2, 3, 1).cpu().numpy(), rxt)
+
+
 def test_group_ties_take_lowest_index(dev):
     """Exact distance ties (duplicated points): deterministic lowest-index choice, as the oracle."""
     from facl_amd import utils_my

@@ -5,10 +5,10 @@ TEST INFRASTRUCTURE (only tests/, __graft_entry__.smoke() and bench.py's cpu_bas
   * SwAV term: ``distributed_sinkhorn`` / ``shoot_infs`` (training_code/cn3d_model_conbag.py:391-425) and the loop block
     cn3d_train_motion_GL.py:239-263.  The two functions import on CPU here: tests/golden/swav.npz holds their outputs
     (tools/make_goldens.py: make_swav) and pins the restatement below.
-  * CLD term: ``KMeans`` / ``grouping`` (cn3d_train_motion_GL.py:36-70) and the loop block :319-326.  They live in the
-    training SCRIPT, which does not import here (its dataset import needs imageio / torchvision: an ordinary
-    ModuleNotFoundError) and the reference holds no fixture for them: PARITY UNPINNED for the CLD term -- restated from the
-    source text only.
+  * CLD term: ``KMeans`` / ``grouping`` (cn3d_train_motion_GL.py:36-70; textually identical twins in utils_my.py:164-197)
+    and the loop block :319-326 (= utils_my.CLD_Loss :152-161).  tests/golden/cld.npz holds the outputs of the training
+    script's own functions (tools/make_goldens.py: make_cld; the script imports with empty harness-side stand-ins for
+    its unused imageio / torchvision imports) and pins the restatement below: labels, centroids, loss, gradient.
 Both terms are switched off in the shipped loop (``swa_if = 0`` :238, ``cld_if = 0`` :319).
 """
 import numpy as np

@@ -1,9 +1,9 @@
 """View construction of one clip: NumPy restatement of the reference's per-sample augmentation.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  **Parity unpinned**: `training_code/cn3D_data_set.py` cannot be
-imported in the build container (its module-level `import imageio` / `torchvision` raise ModuleNotFoundError, ordinary
-missing modules) and the reference holds no fixture for this path, so these functions are restated from the source
-text alone; what the tests pin is HIP == this restatement.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Pinned by tests/golden/views.npz: tools/make_goldens.py imports
+`training_code/cn3D_data_set.py` (with an empty harness-side stand-in for its unused `import imageio`), calls the
+reference class's own get_temporal_augment_data / get_data_train on synthetic clips under np.random.seed and stores
+the float64 outputs; tests/test_oracle_golden.py holds this restatement to them bit for bit.
 
 Follows cn3D_data_set.py:
   get_temporal_augment_data :654-663    jitter_point_cloud :767-778    reverse_transform :708-713

@@ -27,8 +27,33 @@ def test_sinkhorn_vs_reference_golden(tag):
         np.testing.assert_allclose(out.sum(1), 1.0, rtol=1e-5)           # every sample's assignment sums to 1
 
 
+def test_kmeans_and_cld_vs_reference_golden():
+    """facl_kmeans / grouping / cld_loss vs the outputs of the REFERENCE training script's own KMeans / grouping
+    (cn3d_train_motion_GL.py:36-70; tests/golden/cld.npz): labels exact incl. EMPTY clusters (count 1, zero centroid) and
+    K > N, centroids to fp32 rounding, the CLD loop block's loss and its gradient w.r.t. the embeddings."""
+    from facl_amd import swav_cld as P
+    g = load_golden("cld.npz")
+    x = torch.from_numpy(g["km_x"]).to(DEV)
+    for K, it in ((20, 5), (12, 3), (60, 5)):
+        cl, c = P.KMeans(x, K, it)
+        np.testing.assert_array_equal(cl.cpu().numpy(), g[f"km_K{K}_it{it}_labels"])
+        np.testing.assert_allclose(c.detach().cpu().numpy(), g[f"km_K{K}_it{it}_centroids"], rtol=1e-5, atol=1e-6)
+        assert int((c.abs().sum(1) == 0).sum()) == int(g[f"km_K{K}_it{it}_nzero"])
+    B, G, C = g["cld_meta"].tolist()
+    for clusters, iters in ((10, 3), (60, 5)):
+        xr = torch.from_numpy(g["cld_x"]).to(DEV).requires_grad_(True)
+        l0, _ = P.KMeans(xr.detach()[:3 * B], clusters, iters)
+        np.testing.assert_array_equal(l0.cpu().numpy(), g[f"cld_c{clusters}_it{iters}_labels0"])
+        loss = P.cld_loss(xr, B, G, T=0.05, clusters=clusters, num_iters=iters)
+        ref = float(g[f"cld_c{clusters}_it{iters}_loss"])
+        assert abs(loss.item() - ref) < 1e-4 * abs(ref), (loss.item(), ref)
+        loss.backward()
+        gr = g[f"cld_c{clusters}_it{iters}_grad"].astype(np.float64)
+        assert float(np.linalg.norm(xr.grad.cpu().numpy() - gr) / np.linalg.norm(gr)) < 1e-4
+
+
 def test_kmeans_vs_oracle():
-    """facl_kmeans vs oracle KMeans (restated from cn3d_train_motion_GL.py:54-70; parity unpinned by the reference):
+    """facl_kmeans vs oracle KMeans (pinned by cld.npz in tests/test_oracle_golden.py) on a second data set:
     labels exact on separated data, centroids to fp32 rounding, an EMPTY cluster (count 1, zero centroid) included."""
     from facl_amd.swav_cld import KMeans
     from oracle import swav_cld as O

@@ -272,3 +272,46 @@ def test_sinkhorn_oracle_vs_reference_golden():
         if not np.isnan(g[f"{tag}_out"]).all():
             np.testing.assert_allclose(out, g[f"{tag}_out"], rtol=1e-6, atol=0)
     assert int(g["inf_ninf"]) > 0 and np.isnan(g["inf_out"]).all()
+
+
+@pytest.mark.parametrize("seed", [42, 7])
+def test_views_oracle_vs_reference_golden(seed):
+    """oracle/views.py vs the REFERENCE's NTU_RGBD_new.get_temporal_augment_data + get_data_train
+    (cn3D_data_set.py:654-663, :285-350) run on the same clips under np.random.seed(seed) (tests/golden/views.npz):
+    bit-exact float64 views, and the generator stream ends at the same position."""
+    from helpers import golden_view_clips
+    from oracle import views as OV
+    g = load_golden("views.npz")
+    rng = np.random.RandomState(seed)
+    for tag, clip in golden_view_clips(g):
+        got = OV.get_item(rng, *clip)
+        ref = g[f"seed{seed}/{tag}"]
+        assert got.dtype == ref.dtype == np.float64 and got.shape == (10, 512, 4)
+        np.testing.assert_array_equal(got, ref, err_msg=tag)
+    assert rng.rand() == float(g[f"seed{seed}/next_rand"])
+
+
+def test_cld_oracle_vs_reference_golden():
+    """oracle/swav_cld.py KMeans / grouping / cld_loss vs the REFERENCE training script's own functions
+    (cn3d_train_motion_GL.py:36-70 = utils_my.py:164-197; tests/golden/cld.npz): labels exact (incl. the empty-cluster
+    case and K > N), centroids / loss / d loss / d x to fp32 rounding."""
+    from oracle import swav_cld as O
+    g = load_golden("cld.npz")
+    x = torch.from_numpy(g["km_x"])
+    for K, it in ((20, 5), (12, 3), (60, 5)):
+        cl, c = O.KMeans(x, K, it)
+        np.testing.assert_array_equal(cl.numpy(), g[f"km_K{K}_it{it}_labels"])
+        np.testing.assert_allclose(c.numpy(), g[f"km_K{K}_it{it}_centroids"], rtol=1e-6, atol=1e-7)
+        assert int((c.abs().sum(1) == 0).sum()) == int(g[f"km_K{K}_it{it}_nzero"])
+    assert int(g["km_K20_it5_nempty"]) > 0
+    B, G, C = g["cld_meta"].tolist()
+    for clusters, iters in ((10, 3), (60, 5)):
+        xr = torch.from_numpy(g["cld_x"]).clone().requires_grad_(True)
+        loss = O.cld_loss(xr, B, G, T=0.05, clusters=clusters, num_iters=iters)
+        ref = float(g[f"cld_c{clusters}_it{iters}_loss"])
+        assert abs(loss.item() - ref) < 1e-5 * abs(ref)
+        loss.backward()
+        assert rel_err(xr.grad.numpy(), g[f"cld_c{clusters}_it{iters}_grad"]) < 1e-5
+        l0, _ = O.KMeans(torch.from_numpy(g["cld_x"])[:3 * B], clusters, iters)
+        np.testing.assert_array_equal(l0.numpy(), g[f"cld_c{clusters}_it{iters}_labels0"])
+    assert abs(float(g["cld_fn_loss"]) - float(g["cld_c60_it5_loss"])) < 1e-6 * abs(float(g["cld_fn_loss"]))

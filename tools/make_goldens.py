@@ -30,6 +30,25 @@ import utils_my as R_utils                                  # noqa: E402  refere
 import cn3d_model_conbag as R_model                         # noqa: E402  reference
 import cn3d_data_load as R_load                             # noqa: E402  reference
 
+# cn3D_data_set.py:6 imports imageio and cn3d_train_motion_GL.py:24 imports torchvision.transforms; neither module is
+# installed here and neither name is used by any function of those files.  Harness-side EMPTY stand-in modules (same
+# class of patch as the .cuda() identity above) let the two reference modules import, so that their own functions
+# produce the views / CLD fixtures below.
+import types                                                # noqa: E402
+sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+if "torchvision" not in sys.modules:
+    _tv = types.ModuleType("torchvision")
+    _tv.transforms = types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision"] = _tv
+    sys.modules["torchvision.transforms"] = _tv.transforms
+_cvd = os.environ.get("CUDA_VISIBLE_DEVICES")
+import cn3D_data_set as R_data                              # noqa: E402  reference
+import cn3d_train_motion_GL as R_train                      # noqa: E402  reference (sets CUDA_VISIBLE_DEVICES at import)
+if _cvd is None:
+    os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+else:
+    os.environ["CUDA_VISIBLE_DEVICES"] = _cvd
+
 from oracle.weights import formula_state_dict               # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -292,6 +311,92 @@ def make_fc():
     print("fc.npz", {k: np.shape(v) for k, v in out.items()})
 
 
+def synth_clip(seed, dt, P=900, Kp=300, R1=500, R2=200):
+    """The four arrays `__getitem__` loads for one video (cn3D_data_set.py:105-116): (rows, 8) clouds; the temporal
+    channels 4 and 7 carry exact zeros so that get_temporal_augment_data's non-zero filter bites."""
+    r = np.random.RandomState(seed)
+    pts = (r.rand(P, 8) - 0.5).astype(dt)
+    pts[::3, 4] = 0
+    pts[1::4, 7] = 0
+    return pts, (r.rand(Kp, 8) - 0.5).astype(dt), (r.rand(R1, 8) - 0.5).astype(dt), (r.rand(R2, 8) - 0.5).astype(dt)
+
+
+def make_views():
+    """cn3D_data_set.py `__getitem__` body :117-120 = get_temporal_augment_data (:654-663) x2 + get_data_train (:285-350,
+    with jitter_point_cloud :767-778, reverse_transform :708-713, rotate_trans :734-749) of the REFERENCE class on
+    synthetic clouds under np.random.seed.  The instance is made with __new__ (the constructor lists the NTU directory);
+    the methods called use no instance state.  Stored: the clip GENERATOR arguments (the inputs are rebuilt from them by
+    tests/helpers.synth_clip, the same formula), the seed, and the (10,512,4) float64 outputs."""
+    ds = R_data.NTU_RGBD_new.__new__(R_data.NTU_RGBD_new)
+    out = {}
+    cases = [("a", 1, np.float32, dict()), ("b", 2, np.float32, dict(P=777, Kp=513, R1=400, R2=64)),
+             ("c", 3, np.float64, dict(P=2048, Kp=1024)), ("d", 4, np.float64, dict())]
+    for seed_np in (42, 7):
+        np.random.seed(seed_np)
+        for tag, cseed, dt, kw in cases:                    # consecutive __getitem__ calls on ONE generator stream
+            points, key_points, res1, res2 = synth_clip(cseed, dt, **kw)
+            keep = [a.copy() for a in (points, key_points, res1, res2)]
+            time_seg2 = ds.get_temporal_augment_data(points, 4)
+            time_seg4 = ds.get_temporal_augment_data(points, 7)
+            o = ds.get_data_train(points[:, :4], key_points[:, :4], time_seg2[:, :4], time_seg4[:, :4], res1[:, :4],
+                                  res2[:, :4], num_crop=10)
+            assert o.shape == (10, 512, 4) and o.dtype == np.float64
+            assert all(np.array_equal(a, b) for a, b in zip(keep, (points, key_points, res1, res2)))   # inputs untouched
+            out[f"seed{seed_np}/{tag}"] = o
+        out[f"seed{seed_np}/next_rand"] = np.float64(np.random.rand())      # the stream position afterwards
+    out["cases"] = np.array([[c[1], 0 if c[2] is np.float32 else 1, c[3].get("P", 900), c[3].get("Kp", 300),
+                              c[3].get("R1", 500), c[3].get("R2", 200)] for c in cases], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "views.npz"), **out)
+    print("views.npz", {k: np.shape(v) for k, v in out.items()})
+
+
+def make_cld():
+    """cn3d_train_motion_GL.py:36-70 `grouping` / `KMeans` of the REFERENCE training script (textually identical twins
+    live in utils_my.py:164-197: asserted), and the CLD loop block :319-326 = utils_my.CLD_Loss :152-161.  Cases: separated
+    clusters, near-duplicate leading rows (EMPTY clusters: count forced to 1, zero centroid), L2-normalised embeddings at
+    the loop's own settings (clusters=60, 5 iterations, T=0.05) with the gradient of the loss w.r.t. the embeddings."""
+    import inspect
+    assert inspect.getsource(R_train.KMeans) == inspect.getsource(R_utils.KMeans)
+    assert inspect.getsource(R_train.grouping) == inspect.getsource(R_utils.grouping)
+    out = {}
+    rng = np.random.RandomState(0)
+    centres = rng.randn(12, 64).astype(np.float32) * 3
+    x = np.concatenate([centres[i % 12] + 0.1 * rng.randn(64).astype(np.float32) for i in range(96)]).reshape(96, 64)
+    x[:20] = x[0] + 0.01 * rng.randn(20, 64).astype(np.float32)
+    x[1:4] = x[0]                          # exact duplicates among the initial centroids: argmin never picks 1..3 -> EMPTY clusters
+    out["km_x"] = x
+    for K, it in ((20, 5), (12, 3), (60, 5)):
+        cl, c = R_train.KMeans(torch.from_numpy(x), K, it)
+        out[f"km_K{K}_it{it}_labels"] = cl.numpy().astype(np.int64)
+        out[f"km_K{K}_it{it}_centroids"] = c.numpy()
+        out[f"km_K{K}_it{it}_nempty"] = np.int32(K - len(np.unique(cl.numpy())))
+        out[f"km_K{K}_it{it}_nzero"] = np.int32((c.abs().sum(1) == 0).sum().item())
+    assert out["km_K20_it5_nempty"] > 0 and out["km_K20_it5_nzero"] > 0
+    # the loop block on normalised embeddings (x_nor rows are view-major g*B+b)
+    g = torch.Generator().manual_seed(4)
+    B, G, C = 8, 6, 512
+    xn = torch.nn.functional.normalize(torch.randn(G * B, C, generator=g), dim=1)
+    out["cld_x"] = xn.numpy().copy()
+    out["cld_meta"] = np.array([B, G, C], dtype=np.int32)
+    for clusters, iters in ((10, 3), (60, 5)):
+        xr = xn.clone().requires_grad_(True)
+        tot = 0
+        for i in range(G - 4):                                                  # :322-325 with clusters / iters exposed
+            tot = tot + R_train.grouping(xr[i * B:(i + 3) * B], xr[(i + 1) * B:(i + 4) * B], 0.05, 10, clusters, iters)
+        tot.backward()
+        out[f"cld_c{clusters}_it{iters}_loss"] = np.float64(tot.item())
+        out[f"cld_c{clusters}_it{iters}_grad"] = xr.grad.numpy().copy()
+        l1, c1 = R_train.KMeans(xn[:3 * B], clusters, iters)
+        out[f"cld_c{clusters}_it{iters}_labels0"] = l1.numpy().astype(np.int64)
+    # utils_my.CLD_Loss (the loop block as a function: literals 0.05, 10, 60, 5)
+    xr = xn.clone().requires_grad_(True)
+    loss = R_utils.CLD_Loss(0, G, xr, SimpleNamespace(batchSize=B))
+    out["cld_fn_loss"] = np.float64(loss.item())
+    assert abs(out["cld_fn_loss"] - out["cld_c60_it5_loss"]) < 1e-6 * abs(out["cld_fn_loss"])
+    np.savez_compressed(os.path.join(OUT, "cld.npz"), **out)
+    print("cld.npz", {k: np.shape(v) for k, v in out.items()})
+
+
 def _wave_fc(n, key=0):
     from oracle.weights import _hash_uniform
     return (0.02 * _hash_uniform(n, 555 + key)).astype(np.float32)
@@ -305,6 +410,8 @@ def main():
     make_level2()
     make_swav()
     make_fc()
+    make_views()
+    make_cld()
     make_fps()
     make_tiny()
     run_c1(4, False, "d4")

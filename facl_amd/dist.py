@@ -58,6 +58,26 @@ def _use_reduce_scatter(group=None):
 _RS_DECISION = {}
 
 
+# ---- pure layout functions of the embeddings exchange (no collective inside: tests/test_host_logic_cpu.py simulates
+# R in {2,4,8} ranks with lists of tensors and holds the three of them to the single-process gradient)
+def gathered_to_view_major(buf, G, R, Bl, C):
+    """`all_gather_into_tensor` output (rank-major: rank r's (G*Bl, C) view-major rows at [r*G*Bl, (r+1)*G*Bl)) ->
+    the global view-major rows (row = g*(R*Bl) + r*Bl + b), i.e. what one process holding all R*Bl clips would hold."""
+    return buf.view(R, G, Bl, C).permute(1, 0, 2, 3).reshape(G * R * Bl, C)
+
+
+def view_major_to_rank_chunks(g, G, R, Bl, C):
+    """Gradient w.r.t. the global view-major rows -> the contiguous (R*G*Bl, C) input of `reduce_scatter_tensor`:
+    chunk r (rows [r*G*Bl, (r+1)*G*Bl)) holds, in rank r's local view-major order, this rank's contribution to the
+    gradient of rank r's rows.  Exact inverse of `gathered_to_view_major`."""
+    return g.reshape(G, R, Bl, C).permute(1, 0, 2, 3).contiguous().view(R * G * Bl, C)
+
+
+def local_rows_of(g_sum, G, R, r, Bl, C):
+    """The all_reduce + slice form: rank r's (G*Bl, C) rows of the rank-summed global gradient."""
+    return g_sum.reshape(G, R, Bl, C)[:, r].reshape(G * Bl, C)
+
+
 class _AllGatherViewMajor(torch.autograd.Function):
     """(G*B_l, C) view-major local rows -> (G*R*B_l, C) view-major global rows (row = g*(R*B_l) + r*B_l + b).
 
@@ -74,19 +94,19 @@ class _AllGatherViewMajor(torch.autograd.Function):
         buf = torch.empty((R * G * Bl, C), dtype=x.dtype, device=x.device)      # concatenation along dim 0: rank-major
         dist.all_gather_into_tensor(buf, x.contiguous(), group=group)
         ctx.meta = (G, R, r, Bl, C, group)
-        return buf.view(R, G, Bl, C).permute(1, 0, 2, 3).reshape(G * R * Bl, C)  # (G,R,Bl,C) view-major rows
+        return gathered_to_view_major(buf, G, R, Bl, C)
 
     @staticmethod
     def backward(ctx, g):
         G, R, r, Bl, C, group = ctx.meta
         if _use_reduce_scatter(group):
-            gin = g.view(G, R, Bl, C).permute(1, 0, 2, 3).contiguous()          # (R,G,Bl,C): rank-major chunks
+            gin = view_major_to_rank_chunks(g, G, R, Bl, C)
             out = torch.empty((G * Bl, C), dtype=g.dtype, device=g.device)
-            dist.reduce_scatter_tensor(out, gin.view(R * G * Bl, C), op=dist.ReduceOp.SUM, group=group)
+            dist.reduce_scatter_tensor(out, gin, op=dist.ReduceOp.SUM, group=group)
             return out, None, None
         g = g.contiguous()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-        return g.view(G, R, Bl, C)[:, r].reshape(G * Bl, C), None, None
+        return local_rows_of(g, G, R, r, Bl, C), None, None
 
 
 def all_gather_view_major(x, G, group=None):

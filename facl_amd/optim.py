@@ -2,7 +2,8 @@
 
 Same update as ``torch.optim.Adam(params, lr, betas, eps)`` with weight_decay = 0, amsgrad = False, maximize = False
 (cn3d_train_motion_GL.py:180: lr 3e-4, betas (0.5, 0.999), eps 1e-6); the step counter and the learning rate live on
-the device, so a captured HIP graph advances by itself.  Parameters without a gradient are skipped, like torch's."""
+the device, so a captured HIP graph advances its step counter by itself; learning-rate changes reach a replayed graph
+through ``sync_lr()``.  Parameters without a gradient are skipped, like torch's."""
 import ctypes
 
 import torch
@@ -39,7 +40,10 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def _sync_lr(self):
+    def sync_lr(self):
+        """Host -> device copy of ``param_groups[0]["lr"]`` when a schedule changed it.  step() calls it; a captured
+        HIP graph holds no such fill, so whoever REPLAYS a graph with this optimizer inside must call it before each
+        replay (train_common.GraphedStep does): the fill lands on the replay stream, ahead of the graph."""
         lr = float(self.param_groups[0]["lr"])
         if lr != self._lr_host:                              # host -> device only when the schedule changed it
             self._lr.fill_(lr)
@@ -48,7 +52,7 @@ class FusedAdam:
     @torch.no_grad()
     def step(self):
         lib = _lib.load_library()
-        self._sync_lr()
+        self.sync_lr()
         act = [p for p in self.params if p.grad is not None]
         if not act:
             return

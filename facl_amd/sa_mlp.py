@@ -15,12 +15,14 @@ UNIT = 64
 
 
 class _Workspace:
-    """One scratch buffer per device for the partial-sum rows of the reducing kernels."""
+    """Scratch for the partial-sum rows of the reducing kernels: one buffer per (device, stream).  A buffer is only ever
+    touched by launches on the stream it belongs to, so calls on different streams (or threads, each with its own current
+    stream) never share scratch; within one stream the launches are ordered."""
     _ws = {}
 
     @classmethod
     def get(cls, device):
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         if key not in cls._ws:
             n = _lib.load_library().facl_ws_bytes()
             cls._ws[key] = torch.empty(n, dtype=torch.uint8, device=device)

@@ -5,6 +5,8 @@ fused bias / centre term / BN column statistics, dgrad, split-K wgrad); train-mo
 SyncBN hook), BN+ReLU apply, BN+ReLU+max over the S centroids without materialising the activation, and the
 matching backward passes are the row kernels of csrc/rows.hip.
 """
+import threading
+
 import torch
 
 from . import _lib
@@ -19,49 +21,47 @@ from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
 # "x3b": "x3" in the BACKWARD GEMMs only (dgrad / wgrad): forward, features and loss are those of "f32" to the bit, the
 #        gradients carry ~1e-5 relative rounding (far below what Adam's update noise of the reference itself is).
 # The precision in force when a layer's FORWARD runs is recorded on its autograd context and used again by its backward GEMMs.
-_PRECISION = ["f32"]
 PRECISIONS = ("f32", "f16", "x3", "x3b")
-_SUFFIX = {"f32": "", "f16": "_f16", "x3": "_x3", "x3b": ""}          # "x3b" only changes what _PrecGuard installs
+_SUFFIX = {"f32": "", "f16": "_f16", "x3": "_x3", "x3b": ""}
+_LABEL = {"f32": "", "f16": " f16", "x3": " x3", "x3b": ""}
+_SCOPE = threading.local()                  # per-thread scope of `with precision(...)`: read by FORWARD passes only
 
 
 class precision:
+    """``with precision("x3b"): ...`` -- the arithmetic the forward passes entered inside the block record on their
+    autograd context.  Thread-local; the backward never consults it (each pass hands its recorded value to its GEMMs
+    explicitly), so an exception or an out-of-order backward cannot leave a stale mode behind."""
+
     def __init__(self, p):
         if p not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
         self.p = p
 
     def __enter__(self):
-        _PRECISION.append(self.p)
+        stack = _SCOPE.__dict__.setdefault("stack", [])
+        stack.append(self.p)
         return self
 
     def __exit__(self, *exc):
-        _PRECISION.pop()
+        _SCOPE.stack.pop()
         return False
 
 
 def current_precision():
-    return _PRECISION[-1]
+    stack = getattr(_SCOPE, "stack", None)
+    return stack[-1] if stack else "f32"
 
 
-class _PrecGuard:
-    """Scope guard for backward(): restores the precision when the frame that created it returns (or raises)."""
-
-    def __init__(self, p):
-        _PRECISION.append("x3" if p == "x3b" else p)
-
-    def __del__(self):
-        _PRECISION.pop()
+def backward_precision(p):
+    """Arithmetic of the backward GEMMs of a pass whose forward ran under ``p`` ("x3b" = three products there only)."""
+    return "x3" if p == "x3b" else p
 
 
-def _plabel():
-    return {"f32": "", "f16": " f16", "x3": " x3", "x3b": ""}[_PRECISION[-1]]
+def _fn(lib, name, prec):
+    return getattr(lib, name + _SUFFIX[prec])
 
 
-def _fn(lib, name):
-    return getattr(lib, name + _SUFFIX[_PRECISION[-1]])
-
-
-def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
+def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None, prec=None):
     """y = a W^T + bias [+ centers Wc^T] on the hand-written fp32 MFMA GEMM (csrc/gemm.hip); optional fused
     column (sum, sumsq) for the BatchNorm that follows."""
     lib = _lib.load_library()
@@ -70,26 +70,28 @@ def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None):
     y = torch.empty((M, N), dtype=torch.float32, device=a.device)
     sums = torch.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
     ws = _Workspace.get(a.device)
-    with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (M, K, N, _plabel())):
-        _lib.check(_fn(lib, "facl_gemm_fwd")(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
+    prec = current_precision() if prec is None else prec
+    with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (M, K, N, _LABEL[prec])):
+        _lib.check(_fn(lib, "facl_gemm_fwd", prec)(_lib.ptr(a), M, K, _lib.ptr(W), W.stride(0), N, _lib.ptr(bias), None, None,
                                      _lib.ptr(centers), _lib.ptr(Wc), 3 if Wc is not None else 0, _lib.ptr(y),
                                      _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_gemm_fwd")
     return y, sums
 
 
-def gemm_dgrad(dy, W):
+def gemm_dgrad(dy, W, prec=None):
     """da = dy W   (W (N,K) row-major, possibly a column slice of a wider matrix)."""
     lib = _lib.load_library()
     M, N = dy.shape
     K = W.shape[1]
     da = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-    with _lib.timed("facl_gemm_dgrad %dx%dx%d%s" % (M, N, K, _plabel())):
-        _lib.check(_fn(lib, "facl_gemm_dgrad")(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
+    prec = current_precision() if prec is None else prec
+    with _lib.timed("facl_gemm_dgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
+        _lib.check(_fn(lib, "facl_gemm_dgrad", prec)(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
                    "facl_gemm_dgrad")
     return da
 
 
-def gemm_wgrad(dy, a):
+def gemm_wgrad(dy, a, prec=None):
     """dW = dy^T a, contraction over the rows split into slices (deterministic slice-order sum)."""
     lib = _lib.load_library()
     M, N = dy.shape
@@ -98,8 +100,9 @@ def gemm_wgrad(dy, a):
     nz = max(1, min((M + 255) // 256, 512 // tiles))     # tiles * nz = one resident wave of workgroups (2 per CU)
     dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = torch.empty(nz * N * K, dtype=torch.float32, device=dy.device)
-    with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _plabel())):
-        _lib.check(_fn(lib, "facl_gemm_wgrad")(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
+    prec = current_precision() if prec is None else prec
+    with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
+        _lib.check(_fn(lib, "facl_gemm_wgrad", prec)(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
                                        _lib.stream()), "facl_gemm_wgrad")
     return dW
 
@@ -155,7 +158,7 @@ class _LinearBNReLU(torch.autograd.Function):
             centers = centers.contiguous()
         else:
             Wc, Wh = None, W.contiguous()
-        y, sums = gemm_fwd(h, Wh, b, want_stats=training, centers=centers, Wc=Wc)
+        y, sums = gemm_fwd(h, Wh, b, want_stats=training, centers=centers, Wc=Wc, prec=ctx.prec)
         bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
         ctx.centers = centers
         ctx.Wh = Wh
@@ -169,7 +172,7 @@ class _LinearBNReLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da):
-        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
+        bp = backward_precision(ctx.prec)   # the backward GEMMs run in the arithmetic the forward recorded
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
@@ -184,13 +187,13 @@ class _LinearBNReLU(torch.autograd.Function):
         dy = torch.empty_like(y)
         _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                            _lib.stream()), "facl_rows_bwd_apply")
-        dW = gemm_wgrad(dy, h)
+        dW = gemm_wgrad(dy, h, prec=bp)
         if ctx.centers is not None:                                     # xyz columns (C,3): one streaming pass over dy
             dWc = torch.empty((C, 3), dtype=torch.float64, device=y.device)
             _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(ctx.centers), R, C, _lib.ptr(dWc), _lib.ptr(ws),
                                                   _lib.stream()), "facl_rows_center_wgrad")
             dW = torch.cat((dWc.float(), dW), dim=1)
-        dh = gemm_dgrad(dy, ctx.Wh) if ctx.needs_input_grad[0] else None
+        dh = gemm_dgrad(dy, ctx.Wh, prec=bp) if ctx.needs_input_grad[0] else None
         # d(bias) is identically zero in front of a train-mode BN: None leaves the parameter untouched
         return dh, dW, None, dgamma, dbeta, None, None, None, None
 
@@ -218,8 +221,8 @@ class _LinearBNSegmax(torch.autograd.Function):
             y = torch.empty((R, C), dtype=torch.float32, device=h.device)
             sums = torch.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
             ymax = torch.empty((M, C), dtype=torch.float32, device=h.device)
-            with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (R, h.shape[1], C, _plabel())):
-                rc = _fn(lib, "facl_gemm_fwd_segmax")(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b),
+            with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (R, h.shape[1], C, _LABEL[ctx.prec])):
+                rc = _fn(lib, "facl_gemm_fwd_segmax", ctx.prec)(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b),
                                               _lib.ptr(sgn), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(ymax), _lib.ptr(arg),
                                               _lib.ptr(ws), _lib.stream())
             if rc == 0:
@@ -230,7 +233,7 @@ class _LinearBNSegmax(torch.autograd.Function):
             elif rc != -4:                                   # FACL_E_CONFIG: too small for the fused kernel
                 _lib.check(rc, "facl_gemm_fwd_segmax")
         if not fused:
-            y, sums = gemm_fwd(h, W, b, want_stats=training)
+            y, sums = gemm_fwd(h, W, b, want_stats=training, prec=ctx.prec)
             bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
             _lib.check(lib.facl_rows_segmax(_lib.ptr(y), M, S, C, _lib.ptr(bnc), _lib.ptr(xpre), _lib.ptr(arg),
                                             _lib.stream()), "facl_rows_segmax")
@@ -241,7 +244,7 @@ class _LinearBNSegmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxpre, _darg):
-        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
+        bp = backward_precision(ctx.prec)   # the backward GEMMs run in the arithmetic the forward recorded
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
@@ -260,8 +263,8 @@ class _LinearBNSegmax(torch.autograd.Function):
         _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), _lib.stream()),
                    "facl_segmax_bwd_apply")
-        dW = gemm_wgrad(dy, h)
-        dh = gemm_dgrad(dy, W)
+        dW = gemm_wgrad(dy, h, prec=bp)
+        dh = gemm_dgrad(dy, W, prec=bp)
         return dh, dW, None, dgamma, dbeta, None, None, None, None
 
 
@@ -278,16 +281,16 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, h, W, b):
         ctx.prec = current_precision()
         h, W = h.contiguous(), W.contiguous()
-        y, _ = gemm_fwd(h, W, b)
+        y, _ = gemm_fwd(h, W, b, prec=ctx.prec)
         ctx.save_for_backward(h, W)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
+        bp = backward_precision(ctx.prec)   # the backward GEMMs run in the arithmetic the forward recorded
         h, W = ctx.saved_tensors
         dy = dy.contiguous()
-        return gemm_dgrad(dy, W), gemm_wgrad(dy, h), dy.sum(0)
+        return gemm_dgrad(dy, W, prec=bp), gemm_wgrad(dy, h, prec=bp), dy.sum(0)
 
 
 class _FCHead(torch.autograd.Function):
@@ -316,7 +319,7 @@ class _FCHead(torch.autograd.Function):
         arg = torch.empty((B, Cin), dtype=torch.int32, device=x_pre.device)
         _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, Cin, h[M:].data_ptr(), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
         W1, W2 = W1.contiguous(), W2.contiguous()
-        y, _ = gemm_fwd(h, W1, b1)
+        y, _ = gemm_fwd(h, W1, b1, prec=ctx.prec)
         R, C = y.shape
         segs = ((0, M), (M, R))
         a = torch.empty_like(y)
@@ -343,14 +346,14 @@ class _FCHead(torch.autograd.Function):
                                              _lib.ptr(a[r0:r1]), _lib.stream()), "facl_rows_bn_relu")
             bncs.append(bnc)
             counts.append(count)
-        out, _ = gemm_fwd(a, W2, b2)
+        out, _ = gemm_fwd(a, W2, b2, prec=ctx.prec)
         ctx.save_for_backward(h, W1, y, a, W2, arg, *bncs)
         ctx.segs, ctx.counts, ctx.reduce_fn, ctx.training, ctx.G = segs, counts, reduce_fn, training, G
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        _guard = _PrecGuard(ctx.prec)       # backward GEMMs in the forward's arithmetic (popped when the frame ends)
+        bp = backward_precision(ctx.prec)   # the backward GEMMs run in the arithmetic the forward recorded
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
@@ -358,9 +361,9 @@ class _FCHead(torch.autograd.Function):
         ws = _Workspace.get(y.device)
         R, C = y.shape
         dout = dout.contiguous()
-        dW2 = gemm_wgrad(dout, a)
+        dW2 = gemm_wgrad(dout, a, prec=bp)
         db2 = dout.sum(0)
-        dact = gemm_dgrad(dout, W2)
+        dact = gemm_dgrad(dout, W2, prec=bp)
         dy = torch.empty_like(y)
         f32 = dict(dtype=torch.float32, device=y.device)
         sums2 = torch.empty((2, C, 2), dtype=torch.float64, device=y.device)
@@ -375,8 +378,8 @@ class _FCHead(torch.autograd.Function):
             _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
                                                _lib.ptr(kk[i]), _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
         dgamma, dbeta = dga[0] + dga[1], dbe[0] + dbe[1]
-        dW1 = gemm_wgrad(dy, h)
-        dh = gemm_dgrad(dy, W1)
+        dW1 = gemm_wgrad(dy, h, prec=bp)
+        dh = gemm_dgrad(dy, W1, prec=bp)
         M = ctx.segs[0][1]
         B = R - M
         # dL/dx_pre = dh[:M] + (dh[M:] routed to the winning view's row of each (clip, channel))

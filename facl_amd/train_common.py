@@ -178,7 +178,9 @@ class GraphedStep:
     """The whole training iteration (grouping -> forward -> losses -> backward -> Adam) captured once into a HIP
     graph and replayed: ~250 kernel launches per step collapse into one graph launch, so the step is no longer bound
     by host launch latency.  Single-GPU only (collectives stay eager); the optimizer must keep its step counter on the device
-    (facl_amd.optim.FusedAdam, or torch.optim.Adam(capturable=True))."""
+    (facl_amd.optim.FusedAdam, or torch.optim.Adam(capturable=True, lr=<tensor>)).  Learning-rate changes between
+    replays: FusedAdam's device-side lr is refreshed before every replay (`sync_lr`); with torch's capturable Adam only
+    a TENSOR lr updated in place is seen by the graph."""
 
     def __init__(self, step, example_points, G):
         self.step, self.G = step, G
@@ -211,6 +213,10 @@ class GraphedStep:
             np.random.shuffle(order)
         self.points.copy_(out_points, non_blocking=True)
         self.order.copy_(torch.as_tensor(np.asarray(order), dtype=torch.long), non_blocking=True)
+        self.step.epoch = epoch
+        sync = getattr(self.step.optimizer, "sync_lr", None)
+        if sync is not None:
+            sync()                                       # a StepLR change made since the capture reaches k_adam_prep
         self.graph.replay()
         for m in self._bn_modules():                     # host-side num_batches_tracked (netR_FC.1 counts twice)
             m.count_batch()

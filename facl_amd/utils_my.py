@@ -230,7 +230,7 @@ class _ContrastivePair(torch.autograd.Function):
         Bk = J // G
         ctx.mfma = (J % 4 == 0 and C % 4 == 0)     # the MFMA GEMMs contract over multiples of 4; odd toy shapes: library GEMM
         ctx.prec = _tail.current_precision()       # the backward GEMMs run in the forward's arithmetic
-        sim = _tail.gemm_fwd(stacked, keys, None)[0] if ctx.mfma else stacked @ keys.t()     # ((G+1)B, J)  :71 and :103
+        sim = _tail.gemm_fwd(stacked, keys, None, prec=ctx.prec)[0] if ctx.mfma else stacked @ keys.t()     # ((G+1)B, J)  :71 and :103
         dsim = torch.empty_like(sim)
         out = torch.empty(2, dtype=torch.float64, device=dev)
         _lib.check(lib.facl_contrast_pair(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), clip_offset, _lib.ptr(dsim),
@@ -243,7 +243,7 @@ class _ContrastivePair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_c, g_o):
         from . import tail as _tail
-        _guard = _tail._PrecGuard(ctx.prec)
+        bp = _tail.backward_precision(ctx.prec)
         stacked, keys, dsim = ctx.saved_tensors
         # rows [0, G*B) carry the circle loss, rows [G*B, (G+1)*B) the global loss: one scaling launch for both
         lib = _lib.load_library()
@@ -251,8 +251,8 @@ class _ContrastivePair(torch.autograd.Function):
         R, J = dsim.shape
         _lib.check(lib.facl_scale_rows2(_lib.ptr(dsim), _lib.ptr(ds), ctx.GB, R, J, _lib.ptr(g_o.contiguous().float()),
                                         _lib.ptr(g_c.contiguous().float()), _lib.stream()), "facl_scale_rows2")
-        d_stacked = _tail.gemm_dgrad(ds, keys) if ctx.mfma else ds @ keys
-        d_keys = _tail.gemm_wgrad(ds, stacked) if ctx.mfma else ds.t() @ stacked
+        d_stacked = _tail.gemm_dgrad(ds, keys, prec=bp) if ctx.mfma else ds @ keys
+        d_keys = _tail.gemm_wgrad(ds, stacked, prec=bp) if ctx.mfma else ds.t() @ stacked
         if ctx.own_keys:
             d_stacked[:ctx.GB] += d_keys
             d_keys = None

@@ -86,6 +86,63 @@ def test_graph_replay_equals_eager():
     np.testing.assert_allclose(graphed, eager, rtol=2e-5)
 
 
+def test_graph_replay_sees_learning_rate_changes_with_fused_adam():
+    """A StepLR change made AFTER the capture must reach the replayed Adam (FusedAdam keeps lr on the device; the graph
+    holds no fill, GraphedStep refreshes it before each replay).  Parameters after 3 steps with lr 3e-4, 1e-3, 1e-5:
+    graph replay == eager FusedAdam == torch.optim.Adam."""
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.optim import FusedAdam
+    from facl_amd.train_common import ContrastiveStep, GraphedStep
+    from oracle.weights import formula_state_dict
+    D, B, G, N = 4, 2, 3, 512
+    opt = SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
+                          sample_num_level2=64, INPUT_FEATURE_NUM=D, Num_Class=512, batchSize=B, pooling="concatenation",
+                          SAMPLE_NUM=N)
+    torch.manual_seed(0)
+    clips = [torch.rand(B, G, N, D, device=DEV) - 0.5 for _ in range(3)]
+    order = np.array([1, 2, 0])
+    lrs = [3e-4, 1e-3, 1e-5]
+    sd0 = {k: torch.as_tensor(v) for k, v in formula_state_dict(D).items()}
+
+    def make(kind):
+        net = PointNet_Plus(opt, gost=G)
+        net.load_state_dict(sd0)
+        net = net.to(DEV).train()
+        if kind == "torch":
+            optim = torch.optim.Adam(net.parameters(), lr=lrs[0], betas=(0.5, 0.999), eps=1e-6)
+        else:
+            optim = FusedAdam(net.parameters(), lr=lrs[0], betas=(0.5, 0.999), eps=1e-6)
+        return net, ContrastiveStep(net, optim, opt, G)
+
+    def run(net, step, call):
+        for c, lr in zip(clips, lrs):
+            for gr in step.optimizer.param_groups:
+                gr["lr"] = lr
+            call(c)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in net.named_parameters()}
+
+    net_t, step_t = make("torch")
+    p_torch = run(net_t, step_t, lambda c: step_t(c, order=order))
+    net_e, step_e = make("fused")
+    p_eager = run(net_e, step_e, lambda c: step_e(c, order=order))
+    net_g, step_g = make("fused")
+    g = GraphedStep(step_g, clips[0], G)                     # warm-up steps are real steps: reset the state afterwards
+    net_g.load_state_dict(sd0)
+    for st in step_g.optimizer.state.values():
+        for v in st.values():
+            v.zero_()
+    step_g.optimizer._step.zero_()
+    p_graph = run(net_g, step_g, lambda c: g(c, order=order))
+    moved = 0
+    for k in p_eager:
+        ref = p_eager[k]
+        assert torch.allclose(p_graph[k], ref, rtol=1e-5, atol=1e-7), k          # the graph followed the schedule
+        assert torch.allclose(p_torch[k], ref, rtol=2e-3, atol=2e-5), k          # and both follow torch's Adam (update noise)
+        moved += int((ref.cpu() - sd0[k]).abs().max() > 5e-4)
+    assert moved > 10                                         # the 1e-3 step is visible: a stuck 3e-4 / 1e-5 would not pass
+
+
 def test_linear_probe_consumes_extracted_feature_format():
     """(f)-2: the probe trains on vectors in the extraction format (motion ++ appearance, 22*512) and separates
     classes that differ in the features; state_dict keys match the reference's Final_FC."""

@@ -161,6 +161,60 @@ def test_world_size_2_gloo_sharded_loss_equals_global():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+# ---- the embeddings exchange with R simulated ranks (lists of tensors): layout math of BOTH backward branches ----
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_simulated_ranks_reduce_scatter_layout_equals_allreduce_slice_and_single_process(R):
+    """RCCL's backward branch (`reduce_scatter_tensor` on rank-major chunks, dist.py) has never run with R > 1 on
+    hardware; gloo takes all_reduce + slice.  Emulate the collectives exactly -- all_gather_into_tensor = cat of the
+    rank buffers; reduce_scatter_tensor = rank r receives the sum over ranks of chunk r; all_reduce = sum over ranks --
+    and hold the forward layout and both backward branches to the single-process gradient at the global batch."""
+    from facl_amd import dist as fdist
+    from facl_amd.utils_my import circle_contrast, global_contrast
+    torch.manual_seed(R)
+    G, Bl, C = 5, 3, 8
+    Bg = R * Bl
+    order = np.array([4, 1, 0, 3, 2])
+    x_full = torch.randn(G, Bg, C, dtype=torch.float64)
+    xg_full = torch.randn(Bg, C, dtype=torch.float64)
+    # single process, global batch
+    xf = x_full.reshape(G * Bg, C).clone().requires_grad_(True)
+    xgf = xg_full.clone().requires_grad_(True)
+    ref = global_contrast(G, xgf, xf, None) + circle_contrast(G, xf, Bg, order=order)
+    gx_ref, = torch.autograd.grad(ref, xf)
+    # forward: every rank's all_gather_into_tensor output is the cat of the rank-local view-major buffers
+    local = [x_full[:, r * Bl:(r + 1) * Bl].reshape(G * Bl, C).clone() for r in range(R)]
+    buf = torch.cat(local, 0)
+    keys0 = fdist.gathered_to_view_major(buf, G, R, Bl, C)
+    assert torch.equal(keys0, x_full.reshape(G * Bg, C))
+    assert torch.equal(keys0, torch.stack(local, 0).view(R, G, Bl, C).transpose(0, 1).reshape(G * Bg, C))   # stack form
+    # each rank: loss of its own anchors against the gathered keys; gradient w.r.t. the keys (the exchange's input)
+    g_keys, g_direct = [], []
+    for r in range(R):
+        xl = local[r].clone().requires_grad_(True)
+        keys = keys0.clone().requires_grad_(True)
+        xgl = xg_full[r * Bl:(r + 1) * Bl]
+        loss = global_contrast(G, xgl, xl, None, x_keys=keys, clip_offset=r * Bl) + \
+            circle_contrast(G, xl, Bl, order=order, x_keys=keys, clip_offset=r * Bl)
+        gk, gl = torch.autograd.grad(loss, (keys, xl))
+        g_keys.append(gk)
+        g_direct.append(gl)
+    # branch A (RCCL): reduce_scatter_tensor over rank-major chunks
+    chunks = [fdist.view_major_to_rank_chunks(g, G, R, Bl, C) for g in g_keys]
+    assert all(c.is_contiguous() and c.shape == (R * G * Bl, C) for c in chunks)
+    rs = [sum(c[r * G * Bl:(r + 1) * G * Bl] for c in chunks) for r in range(R)]
+    # branch B (gloo): all_reduce + slice
+    g_sum = sum(g_keys)
+    ar = [fdist.local_rows_of(g_sum, G, R, r, Bl, C) for r in range(R)]
+    for r in range(R):
+        assert torch.allclose(rs[r], ar[r], rtol=1e-12, atol=1e-14), r
+        total = (rs[r] + g_direct[r]) / R                               # + the direct path, then the DDP average
+        want = gx_ref.view(G, Bg, C)[:, r * Bl:(r + 1) * Bl].reshape(G * Bl, C)
+        assert torch.allclose(total, want, rtol=1e-9, atol=1e-12), r
+    # the two layout functions are exact inverses
+    t = torch.randn(G * Bg, C)
+    assert torch.equal(fdist.gathered_to_view_major(fdist.view_major_to_rank_chunks(t, G, R, Bl, C), G, R, Bl, C), t)
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/r02_bench_line.json (the last bench.py line measured on an MI355X) carries every field of the driver's
     contract plus the roofline / cpu_baseline objects; `roofline` is the LONGEST measured kernel (round-1 defect: it was

@@ -128,6 +128,43 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- debug switch: poisoned scratch ------------------------------------------------------------------------------------
+# Every output / scratch tensor the host layer hands to a kernel is `torch.empty` (the kernels write every element
+# they later read).  With POISON on (FACL_POISON=1, or `with poisoned():`) those tensors and the partial-sum workspace are
+# filled with NaN / 0xFF bytes first, so a partial row or an output element that a launch leaves unwritten for some
+# ragged shape shows up as NaN in the results instead of silently reading whatever the allocator recycled.
+POISON = os.environ.get("FACL_POISON", "0") not in ("", "0")
+
+
+class poisoned:
+    def __enter__(self):
+        global POISON
+        self.prev, POISON = POISON, True
+        return self
+
+    def __exit__(self, *exc):
+        global POISON
+        POISON = self.prev
+        return False
+
+
+def _poison(t):
+    if POISON and t.numel():
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        else:
+            t.view(torch.uint8).fill_(0xFF)
+    return t
+
+
+def empty(*size, **kw):
+    return _poison(torch.empty(*size, **kw))
+
+
+def empty_like(t, **kw):
+    return _poison(torch.empty_like(t, **kw))
+
+
 def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

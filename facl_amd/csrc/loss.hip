@@ -175,10 +175,14 @@ __global__ __launch_bounds__(1024) void k_contrast_reg(const float* __restrict__
 struct PairSpec {
     int nA, nS, slot_rows, circle, G, B, Bk, J, myclip, n;
     const long long* order;
-    __device__ __forceinline__ int row_block(int i) const { return circle ? (int)order[i] : G; }
+    __device__ __forceinline__ int ord(int i) const {            // clamped: a corrupt entry cannot address outside sim / dsim
+        const long long o = order[i];
+        return o < 0 ? 0 : (o >= G ? G - 1 : (int)o);
+    }
+    __device__ __forceinline__ int row_block(int i) const { return circle ? ord(i) : G; }
     __device__ __forceinline__ size_t pos_index(int s) const {
         const int rb = row_block(slot_rows ? s : 0);
-        const int col = (circle ? (int)order[s + 1] : s) * Bk + myclip;
+        const int col = (circle ? ord(s + 1) : s) * Bk + myclip;
         return (size_t)(rb * B + n) * J + col;
     }
 };
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(1024) void k_contrast_pair_reg(const float* __restr
         }
     }
     if (sp.circle) {                                       // the view that is no anchor: zero gradient row
-        float* z = dsim + (size_t)((int)order[G - 1] * B + n) * J;
+        float* z = dsim + (size_t)(sp.ord(G - 1) * B + n) * J;
         for (int j = threadIdx.x; j < J; j += 1024) z[j] = 0.f;
     }
     __syncthreads();                                       // the positives overwrite zeros written just above
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void k_contrast_pair(const float* __restrict__
         for (int j = threadIdx.x; j < J; j += 256) dsim[ro + j] = (j % Bk == myclip) ? 0.f : dlse * __expf(sim[ro + j] - lse);
     }
     if (sp.circle) {
-        float* z = dsim + (size_t)((int)order[G - 1] * B + n) * J;
+        float* z = dsim + (size_t)(sp.ord(G - 1) * B + n) * J;
         for (int j = threadIdx.x; j < J; j += 256) z[j] = 0.f;
     }
     __syncthreads();
@@ -330,6 +334,7 @@ extern "C" int facl_contrast(const float* sim, int R, int J, int B, int Bk, int 
     if (!sim || !poscol || !dsim || !loss || !ws) return FACL_E_NULL;
     if (B < 1 || nA < 1 || nS < 1 || R != nA * B || J < 1 || Bk < 1 || J % Bk) return FACL_E_SHAPE;
     if (slot_rows && nS != nA) return FACL_E_SHAPE;
+    if (clip_offset < 0 || clip_offset + B > Bk) return FACL_E_SHAPE;        // the local clips must be columns of the keys
     hipStream_t st = (hipStream_t)stream;
     if ((long long)nA * J <= (long long)CK * 1024 && nS <= 1024)
         hipLaunchKernelGGL(k_contrast_reg, dim3(B), dim3(1024), 0, st, sim, J, B, Bk, nA, nS, slot_rows, poscol, clip_offset,
@@ -346,6 +351,7 @@ extern "C" int facl_contrast_pair(const float* sim, int G, int B, int Bk, int J,
                                   float* dsim, double* losses /* [loss_c, loss_circle] */, void* ws, void* stream) {
     if (!sim || !order || !dsim || !losses || !ws) return FACL_E_NULL;
     if (G < 2 || B < 1 || Bk < 1 || J != G * Bk) return FACL_E_SHAPE;
+    if (clip_offset < 0 || clip_offset + B > Bk) return FACL_E_SHAPE;        // the local clips must be columns of the keys
     hipStream_t st = (hipStream_t)stream;
     if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024)
         hipLaunchKernelGGL(k_contrast_pair_reg, dim3(2 * B), dim3(1024), 0, st, sim, G, B, Bk, J, (const long long*)order,

@@ -42,7 +42,7 @@ class _GatherRows(torch.autograd.Function):
         feat = feat.contiguous()
         M, S2, K = idx.shape
         C = feat.shape[1]
-        out = torch.empty((M * S2 * K, C), dtype=torch.float32, device=feat.device)
+        out = _lib.empty((M * S2 * K, C), dtype=torch.float32, device=feat.device)
         _lib.check(lib.facl_gather_rows(_lib.ptr(feat), C, M, S1, C, _lib.ptr(idx), S2 * K, None, _lib.ptr(out), C, 0,
                                         _lib.stream()), "facl_gather_rows")
         ctx.save_for_backward(idx)
@@ -55,7 +55,7 @@ class _GatherRows(torch.autograd.Function):
         idx, = ctx.saved_tensors
         M, S1, C, rpc = ctx.dims
         drows = drows.contiguous()
-        dfeat = torch.empty((M * S1, C), dtype=torch.float32, device=drows.device)
+        dfeat = _lib.empty((M * S1, C), dtype=torch.float32, device=drows.device)
         _lib.check(lib.facl_scatter_rows(_lib.ptr(drows), C, 0, M, S1, C, _lib.ptr(idx), rpc, _lib.ptr(dfeat), _lib.stream()),
                    "facl_scatter_rows")
         return dfeat, None, None
@@ -81,7 +81,7 @@ def _group_points_2(points, sample_num_level2, K, r2):
     rows = points.detach().float().transpose(1, 2).contiguous()                    # (B,S1,3+C); a no-copy if it was a view of this
     xyz = rows[:, :, :3].contiguous()
     xt, yt, idx = knn_radius_group(xyz, S2, K, float(r2), want_idx=True)
-    out = torch.empty((B, S2, K, C3), dtype=torch.float32, device=points.device)
+    out = _lib.empty((B, S2, K, C3), dtype=torch.float32, device=points.device)
     xyz_g = xt.permute(0, 2, 3, 1).contiguous()
     if C3 > 3:
         _lib.check(lib.facl_gather_rows(rows[:, :, 3:].data_ptr(), C3, B, S1, C3 - 3, _lib.ptr(idx), S2 * K, _lib.ptr(xyz_g),

@@ -17,7 +17,7 @@ def farthest_point_sampling_batch(xyz, sample_num, start_idx):
     start = torch.as_tensor(start_idx, device=xyz.device).to(torch.int32).contiguous()
     if start.numel() != M:
         raise ValueError("start_idx must have one entry per cloud")
-    out = torch.empty((M, sample_num), dtype=torch.int32, device=xyz.device)
+    out = _lib.empty((M, sample_num), dtype=torch.int32, device=xyz.device)
     lib = _lib.load_library()
     fn = {torch.float32: lib.facl_fps_f32, torch.float64: lib.facl_fps_f64}.get(xyz.dtype)
     if fn is None:
@@ -36,7 +36,7 @@ def farthest_point_sampling_fast(pc, sample_num, start_idx=None):
 
 
 def _reorder(pts, picks, m):
-    out = torch.empty_like(pts)
+    out = _lib.empty_like(pts)
     b, N, D = pts.shape
     lib = _lib.load_library()
     _lib.check(lib.facl_fps_reorder(_lib.ptr(pts), b, N, D, _lib.ptr(picks), m, _lib.ptr(out), _lib.stream()),

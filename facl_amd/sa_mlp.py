@@ -26,12 +26,14 @@ class _Workspace:
         if key not in cls._ws:
             n = _lib.load_library().facl_ws_bytes()
             cls._ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
+        if _lib.POISON:
+            cls._ws[key].fill_(0xFF)                     # NaN bytes: every partial row a reduction reads must be rewritten
         return cls._ws[key]
 
 
 def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM):
     lib = _lib.load_library()
-    bnc = torch.empty((5, C), dtype=torch.float32, device=sums.device)
+    bnc = _lib.empty((5, C), dtype=torch.float32, device=sums.device)
     _lib.check(lib.facl_bn_finalize(_lib.ptr(sums), C, float(count), _lib.ptr(gamma), _lib.ptr(beta), BN_EPS,
                                     momentum, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(bnc),
                                     _lib.stream()), "facl_bn_finalize")
@@ -40,7 +42,7 @@ def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentu
 
 def _bn_eval(C, gamma, beta, running_mean, running_var):
     lib = _lib.load_library()
-    bnc = torch.empty((5, C), dtype=torch.float32, device=gamma.device)
+    bnc = _lib.empty((5, C), dtype=torch.float32, device=gamma.device)
     _lib.check(lib.facl_bn_eval_consts(C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
                                        _lib.ptr(running_var), BN_EPS, _lib.ptr(bnc), _lib.stream()),
                "facl_bn_eval_consts")
@@ -97,13 +99,13 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     W3 = p["W3"].reshape(256, 64)
     ctx = {}
     if training:
-        mom = torch.empty(D + D * D, **f64)
+        mom = _lib.empty(D + D * D, **f64)
         _lib.check(lib.facl_sa_x_moments(_lib.ptr(x_rows), P, D, _lib.ptr(mom), _lib.ptr(ws), st), "facl_sa_x_moments")
         ctx["mom_local"] = mom
         if reduce_fn is not None:
             mom = reduce_fn(mom.clone())
             count = float(P) * reduce_fn.world_size          # every rank holds the same number of positions
-        sums1 = torch.empty((64, 2), **f64)
+        sums1 = _lib.empty((64, 2), **f64)
         _lib.check(lib.facl_bn1_sums_from_moments(_lib.ptr(mom), count, D, _lib.ptr(W1), _lib.ptr(p["b1"]),
                                                   _lib.ptr(sums1), st), "facl_bn1_sums_from_moments")
         direct = update_running and rep == 1
@@ -115,11 +117,11 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         ctx["mom"] = mom
     else:
         bnc1 = _bn_eval(64, p["g1"], p["be1"], p["rm1"], p["rv1"])
-    l1tab = torch.empty((64, 8), dtype=torch.float32, device=dev)
+    l1tab = _lib.empty((64, 8), dtype=torch.float32, device=dev)
     _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(p["b1"]), D, _lib.ptr(bnc1[2]), _lib.ptr(bnc1[3]),
                                  _lib.ptr(l1tab), st), "facl_sa_l1tab")
-    y2f = torch.empty(nunits * UNIT * 64, dtype=torch.float32, device=dev)
-    sums2 = torch.empty((64, 2), **f64) if training else None
+    y2f = _lib.empty(nunits * UNIT * 64, dtype=torch.float32, device=dev)
+    sums2 = _lib.empty((64, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd2"):
         _lib.check(lib.facl_sa_fwd2(_lib.ptr(x_rows), nunits, D, _lib.ptr(l1tab), _lib.ptr(W2), _lib.ptr(p["b2"]),
                                     _lib.ptr(y2f), _lib.ptr(sums2), _lib.ptr(ws), st), "facl_sa_fwd2")
@@ -133,9 +135,9 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     else:
         bnc2 = _bn_eval(64, p["g2"], p["be2"], p["rm2"], p["rv2"])
     sgn3 = p["g3"]                                                    # the kernels take sign(gamma3) themselves (sign(0) = +1)
-    ymax = torch.empty((nunits, 256), dtype=torch.float32, device=dev)
-    arg = torch.empty((nunits, 256), dtype=torch.uint8, device=dev)
-    sums3 = torch.empty((256, 2), **f64) if training else None
+    ymax = _lib.empty((nunits, 256), dtype=torch.float32, device=dev)
+    arg = _lib.empty((nunits, 256), dtype=torch.uint8, device=dev)
+    sums3 = _lib.empty((256, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd3"):
         # dense configuration: fp16-input 64->256 layer; "x3": the opt-in three-product variant (tail.precision)
         fwd3 = {"f32": lib.facl_sa_fwd3, "f16": lib.facl_sa_fwd3_f16, "x3": lib.facl_sa_fwd3_x3, "x3b": lib.facl_sa_fwd3}[precision]
@@ -156,7 +158,7 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         ngroups = nunits // R
         ymax_g, rsel = ymax.view(ngroups, R, 256).max(dim=1)
         ymax_g = ymax_g.contiguous()
-    pooled = torch.empty((ngroups, 256), dtype=torch.float32, device=dev)
+    pooled = _lib.empty((ngroups, 256), dtype=torch.float32, device=dev)
     _lib.check(lib.facl_sa_pool(_lib.ptr(ymax_g), ngroups, 256, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(pooled), st),
                "facl_sa_pool")
     ctx.update(y2f=y2f, ymax=ymax_g, arg=arg, bnc1=bnc1, bnc2=bnc2, bnc3=bnc3, sgn3=sgn3, l1tab=l1tab, count=count,
@@ -191,8 +193,8 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
 
     # ---- pass 0: sparse values + (dbeta3, dgamma3)
     ngroups, R = ctx["ngroups"], ctx["R"]
-    coef = torch.empty((ngroups, 256), **f32)
-    sums0 = torch.empty((256, 2), **f64)
+    coef = _lib.empty((ngroups, 256), **f32)
+    sums0 = _lib.empty((256, 2), **f64)
     _lib.check(lib.facl_sa_bwd0(ptr(dpooled), ptr(ctx["ymax"]), ngroups, ptr(bnc3), ptr(coef), ptr(sums0), ptr(ws), st),
                "facl_sa_bwd0")
     if R > 1:                                    # route each group's sparse value to the unit that won the max
@@ -202,13 +204,13 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     sums0_l = sums0
     if reduce_fn is not None:
         sums0 = reduce_fn(sums0.clone())
-    G3, h3 = torch.empty((64, 64), **f32), torch.empty(64, **f32)
+    G3, h3 = _lib.empty((64, 64), **f32), _lib.empty(64, **f32)
     _lib.check(lib.facl_sa_bwd_consts3(ptr(sums0), ptr(bnc3), ptr(W3), ptr(p["b3"]), P, ptr(G3), ptr(h3), st),
                "facl_sa_bwd_consts3")
 
     # ---- pass 1: dz2 + (dbeta2, dgamma2)
-    dz2f = torch.empty_like(ctx["y2f"])
-    sums1 = torch.empty((64, 2), **f64)
+    dz2f = _lib.empty_like(ctx["y2f"])
+    sums1 = _lib.empty((64, 2), **f64)
     with _lib.timed("facl_sa_bwd1"):
         _lib.check(lib.facl_sa_bwd1(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(G3), ptr(h3), ptr(W3), ptr(coef),
                                     ptr(ctx["arg"]), ptr(dz2f), ptr(sums1), ptr(ws), st), "facl_sa_bwd1")
@@ -217,15 +219,15 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
         sums1 = reduce_fn(sums1.clone())
 
     # ---- layer-3 weight gradient ingredients: sparse gather, Gram, sum a2
-    out3 = torch.empty(256 * 64 + 64 * 64 + 64, **f64)
+    out3 = _lib.empty(256 * 64 + 64 * 64 + 64, **f64)
     with _lib.timed("facl_sa_bwd_w3"):
         _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
                    "facl_sa_bwd_w3")
 
     # ---- pass 2: dy2, da1, dz1, dW2, R1
-    bw2 = torch.empty((4, 64), **f32)
+    bw2 = _lib.empty((4, 64), **f32)
     _lib.check(lib.facl_sa_bwd_consts2(ptr(sums1), ptr(bnc2), P, ptr(bw2), st), "facl_sa_bwd_consts2")
-    out2 = torch.empty(64 * 64 + 8 * 64, **f64)
+    out2 = _lib.empty(64 * 64 + 8 * 64, **f64)
     with _lib.timed("facl_sa_bwd2"):
         _lib.check(lib.facl_sa_bwd2(ptr(dz2f), ptr(ctx["y2f"]), ptr(x_rows), nunits, D, ptr(bw2), ptr(W2), ptr(ctx["l1tab"]),
                                     ptr(out2), ptr(ws), st), "facl_sa_bwd2")
@@ -233,9 +235,9 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     if reduce_fn is not None:
         R1_g = reduce_fn(R1_g.clone())
 
-    g = {"W3": torch.empty_like(p["W3"]), "g3": torch.empty(256, **f32), "be3": torch.empty(256, **f32),
-         "W2": torch.empty_like(p["W2"]), "g2": torch.empty(64, **f32), "be2": torch.empty(64, **f32),
-         "W1": torch.empty_like(p["W1"]), "g1": torch.empty(64, **f32), "be1": torch.empty(64, **f32),
+    g = {"W3": _lib.empty_like(p["W3"]), "g3": _lib.empty(256, **f32), "be3": _lib.empty(256, **f32),
+         "W2": _lib.empty_like(p["W2"]), "g2": _lib.empty(64, **f32), "be2": _lib.empty(64, **f32),
+         "W1": _lib.empty_like(p["W1"]), "g1": _lib.empty(64, **f32), "be1": _lib.empty(64, **f32),
          # d(bias) of a conv that feeds a train-mode BN is identically zero: None (the parameter is left untouched)
          "b1": None, "b2": None, "b3": None}
     _lib.check(lib.facl_sa_bwd_final(ptr(out3), ptr(sums0), ptr(sums0_l), ptr(bnc3), ptr(W3), ptr(p["b3"]), ptr(out2),

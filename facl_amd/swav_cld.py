@@ -28,8 +28,8 @@ def distributed_sinkhorn(Q, nmb_iters):
     with torch.no_grad():
         Qc = Q.detach().float().contiguous()
         R, C = Qc.shape
-        scratch = torch.empty(R * C + R, dtype=torch.float32, device=Q.device)
-        out = torch.empty((C, R), dtype=torch.float32, device=Q.device)
+        scratch = _lib.empty(R * C + R, dtype=torch.float32, device=Q.device)
+        out = _lib.empty((C, R), dtype=torch.float32, device=Q.device)
         _lib.check(lib.facl_sinkhorn(_lib.ptr(Qc), R, C, int(nmb_iters), _lib.ptr(scratch), _lib.ptr(out), _lib.stream()),
                    "facl_sinkhorn")
     return out
@@ -57,9 +57,9 @@ def KMeans(x, K=10, Niters=10, verbose=False):
     lib = _lib.load_library()
     xc = x.detach().float().contiguous()
     N, D = xc.shape
-    labels = torch.empty(N, dtype=torch.int32, device=x.device)
-    cent = torch.empty((K, D), dtype=torch.float32, device=x.device)
-    counts = torch.empty(K, dtype=torch.int32, device=x.device)
+    labels = _lib.empty(N, dtype=torch.int32, device=x.device)
+    cent = _lib.empty((K, D), dtype=torch.float32, device=x.device)
+    counts = _lib.empty(K, dtype=torch.int32, device=x.device)
     _lib.check(lib.facl_kmeans(_lib.ptr(xc), N, D, int(K), int(Niters), _lib.ptr(labels), _lib.ptr(cent), _lib.ptr(counts),
                                _lib.stream()), "facl_kmeans")
     return labels.long(), _SegmentMean.apply(x, labels, cent, counts)

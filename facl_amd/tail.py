@@ -67,8 +67,8 @@ def gemm_fwd(a, W, bias, want_stats=False, centers=None, Wc=None, prec=None):
     lib = _lib.load_library()
     M, K = a.shape
     N = W.shape[0]
-    y = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    sums = torch.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
+    y = _lib.empty((M, N), dtype=torch.float32, device=a.device)
+    sums = _lib.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
     ws = _Workspace.get(a.device)
     prec = current_precision() if prec is None else prec
     with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (M, K, N, _LABEL[prec])):
@@ -83,7 +83,7 @@ def gemm_dgrad(dy, W, prec=None):
     lib = _lib.load_library()
     M, N = dy.shape
     K = W.shape[1]
-    da = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    da = _lib.empty((M, K), dtype=torch.float32, device=dy.device)
     prec = current_precision() if prec is None else prec
     with _lib.timed("facl_gemm_dgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
         _lib.check(_fn(lib, "facl_gemm_dgrad", prec)(_lib.ptr(dy), M, N, W.data_ptr(), W.stride(0), K, _lib.ptr(da), _lib.stream()),
@@ -98,8 +98,8 @@ def gemm_wgrad(dy, a, prec=None):
     K = a.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     nz = max(1, min((M + 255) // 256, 512 // tiles))     # tiles * nz = one resident wave of workgroups (2 per CU)
-    dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-    slices = torch.empty(nz * N * K, dtype=torch.float32, device=dy.device)
+    dW = _lib.empty((N, K), dtype=torch.float32, device=dy.device)
+    slices = _lib.empty(nz * N * K, dtype=torch.float32, device=dy.device)
     prec = current_precision() if prec is None else prec
     with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
         _lib.check(_fn(lib, "facl_gemm_wgrad", prec)(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
@@ -110,7 +110,7 @@ def gemm_wgrad(dy, a, prec=None):
 def _stats(y, ws):
     lib = _lib.load_library()
     R, C = y.shape
-    sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+    sums = _lib.empty((C, 2), dtype=torch.float64, device=y.device)
     _lib.check(lib.facl_rows_stats(_lib.ptr(y), R, C, _lib.ptr(sums), _lib.ptr(ws), _lib.stream()), "facl_rows_stats")
     return sums
 
@@ -119,7 +119,7 @@ def _bn_bwd_consts(sums, C, count, reduce_fn):
     """(dbeta, dgamma) fp64 sums -> fp32 parameter gradients of THIS rank + kk (2,C) = SyncBN-reduced sums / P."""
     lib = _lib.load_library()
     f32 = dict(dtype=torch.float32, device=sums.device)
-    dbeta, dgamma, kk = torch.empty(C, **f32), torch.empty(C, **f32), torch.empty((2, C), **f32)
+    dbeta, dgamma, kk = _lib.empty(C, **f32), _lib.empty(C, **f32), _lib.empty((2, C), **f32)
     sums_g = reduce_fn(sums.clone()) if reduce_fn is not None else sums
     _lib.check(lib.facl_bn_bwd_consts(_lib.ptr(sums), _lib.ptr(sums_g), C, float(count), _lib.ptr(dbeta), _lib.ptr(dgamma),
                                       _lib.ptr(kk), _lib.stream()), "facl_bn_bwd_consts")
@@ -163,7 +163,7 @@ class _LinearBNReLU(torch.autograd.Function):
         ctx.centers = centers
         ctx.Wh = Wh
         R, C = y.shape
-        a = torch.empty_like(y)
+        a = _lib.empty_like(y)
         _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y), R, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a),
                                          _lib.stream()), "facl_rows_bn_relu")
         ctx.save_for_backward(h, W, y, bnc)
@@ -180,16 +180,16 @@ class _LinearBNReLU(torch.autograd.Function):
         ws = _Workspace.get(y.device)
         R, C = y.shape
         da = da.contiguous()
-        sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+        sums = _lib.empty((C, 2), dtype=torch.float64, device=y.device)
         _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws),
                                            _lib.stream()), "facl_rows_bwd_stats")
         dbeta, dgamma, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)   # parameter gradients stay local sums
-        dy = torch.empty_like(y)
+        dy = _lib.empty_like(y)
         _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), R, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                            _lib.stream()), "facl_rows_bwd_apply")
         dW = gemm_wgrad(dy, h, prec=bp)
         if ctx.centers is not None:                                     # xyz columns (C,3): one streaming pass over dy
-            dWc = torch.empty((C, 3), dtype=torch.float64, device=y.device)
+            dWc = _lib.empty((C, 3), dtype=torch.float64, device=y.device)
             _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(ctx.centers), R, C, _lib.ptr(dWc), _lib.ptr(ws),
                                                   _lib.stream()), "facl_rows_center_wgrad")
             dW = torch.cat((dWc.float(), dW), dim=1)
@@ -211,16 +211,16 @@ class _LinearBNSegmax(torch.autograd.Function):
         W = W.contiguous()
         R, C = h.shape[0], W.shape[0]
         M = R // S
-        xpre = torch.empty((M, C), dtype=torch.float32, device=h.device)
-        arg = torch.empty((M, C), dtype=torch.int32, device=h.device)
+        xpre = _lib.empty((M, C), dtype=torch.float32, device=h.device)
+        arg = _lib.empty((M, C), dtype=torch.int32, device=h.device)
         fused = False
         if S == 64 and R % 64 == 0:
             # max over the 64 centroid rows of each cloud inside the GEMM epilogue (sign(gamma) is known before the
             # statistics are; BN + ReLU are monotone per channel): y is not re-read by a pooling pass
             sgn = gamma.detach()                              # the kernel takes sign(gamma) itself (sign(0) = +1)
-            y = torch.empty((R, C), dtype=torch.float32, device=h.device)
-            sums = torch.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
-            ymax = torch.empty((M, C), dtype=torch.float32, device=h.device)
+            y = _lib.empty((R, C), dtype=torch.float32, device=h.device)
+            sums = _lib.empty((C, 2), dtype=torch.float64, device=h.device) if training else None
+            ymax = _lib.empty((M, C), dtype=torch.float32, device=h.device)
             with _lib.timed("facl_gemm_fwd %dx%dx%d%s" % (R, h.shape[1], C, _LABEL[ctx.prec])):
                 rc = _fn(lib, "facl_gemm_fwd_segmax", ctx.prec)(_lib.ptr(h), R, h.shape[1], _lib.ptr(W), W.stride(0), C, _lib.ptr(b),
                                               _lib.ptr(sgn), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(ymax), _lib.ptr(arg),
@@ -254,12 +254,12 @@ class _LinearBNSegmax(torch.autograd.Function):
         S = ctx.S
         M = R // S
         dxpre = dxpre.contiguous()
-        sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+        sums = _lib.empty((C, 2), dtype=torch.float64, device=y.device)
         _lib.check(lib.facl_segmax_bwd_stats(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
                    "facl_segmax_bwd_stats")
         dbeta, dgamma, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)   # parameter gradients stay local sums
-        dy = torch.empty_like(y)
+        dy = _lib.empty_like(y)
         _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y), _lib.ptr(arg), M, S, C,
                                              _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), _lib.stream()),
                    "facl_segmax_bwd_apply")
@@ -314,20 +314,20 @@ class _FCHead(torch.autograd.Function):
         x_pre = x_pre.contiguous()
         M, Cin = x_pre.shape
         B = M // G
-        h = torch.empty((M + B, Cin), dtype=torch.float32, device=x_pre.device)
+        h = _lib.empty((M + B, Cin), dtype=torch.float32, device=x_pre.device)
         h[:M].copy_(x_pre)
-        arg = torch.empty((B, Cin), dtype=torch.int32, device=x_pre.device)
+        arg = _lib.empty((B, Cin), dtype=torch.int32, device=x_pre.device)
         _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, Cin, h[M:].data_ptr(), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
         W1, W2 = W1.contiguous(), W2.contiguous()
         y, _ = gemm_fwd(h, W1, b1, prec=ctx.prec)
         R, C = y.shape
         segs = ((0, M), (M, R))
-        a = torch.empty_like(y)
+        a = _lib.empty_like(y)
         bncs, counts = [], []
         if training:
             # both segments' statistics first, ONE SyncBN all-reduce for the pair, then the two finalisations in the
             # reference's order (view rows :228, clip rows :229: the running statistics are updated twice)
-            sums2 = torch.empty((2, C, 2), dtype=torch.float64, device=y.device)
+            sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
             for i, (r0, r1) in enumerate(segs):
                 _lib.check(lib.facl_rows_stats(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()),
                            "facl_rows_stats")
@@ -364,14 +364,14 @@ class _FCHead(torch.autograd.Function):
         dW2 = gemm_wgrad(dout, a, prec=bp)
         db2 = dout.sum(0)
         dact = gemm_dgrad(dout, W2, prec=bp)
-        dy = torch.empty_like(y)
+        dy = _lib.empty_like(y)
         f32 = dict(dtype=torch.float32, device=y.device)
-        sums2 = torch.empty((2, C, 2), dtype=torch.float64, device=y.device)
+        sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
         for i, ((r0, r1), bnc) in enumerate(zip(ctx.segs, (bnc_a, bnc_b))):
             _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
                                                _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()), "facl_rows_bwd_stats")
         sums2_g = ctx.reduce_fn(sums2.clone()) if ctx.reduce_fn is not None else sums2       # one all-reduce for the pair
-        dbe, dga, kk = torch.empty((2, C), **f32), torch.empty((2, C), **f32), torch.empty((2, 2, C), **f32)
+        dbe, dga, kk = _lib.empty((2, C), **f32), _lib.empty((2, C), **f32), _lib.empty((2, 2, C), **f32)
         for i, ((r0, r1), bnc, count) in enumerate(zip(ctx.segs, (bnc_a, bnc_b), ctx.counts)):
             _lib.check(lib.facl_bn_bwd_consts(_lib.ptr(sums2[i]), _lib.ptr(sums2_g[i]), C, float(count), _lib.ptr(dbe[i]),
                                               _lib.ptr(dga[i]), _lib.ptr(kk[i]), _lib.stream()), "facl_bn_bwd_consts")
@@ -407,8 +407,8 @@ class _NormalizeMap(torch.autograd.Function):
         x, Wm = x.contiguous(), Wm.contiguous()
         M, C = x.shape
         K = Wm.shape[0]
-        xn = torch.empty_like(x)
-        code = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        xn = _lib.empty_like(x)
+        code = _lib.empty((M, K), dtype=torch.float32, device=x.device)
         _lib.check(lib.facl_normalize_map(_lib.ptr(x), M, C, _lib.ptr(Wm), K, _lib.ptr(xn), _lib.ptr(code), _lib.stream()),
                    "facl_normalize_map")
         ctx.save_for_backward(x, xn, Wm)
@@ -439,8 +439,8 @@ class _ViewMax(torch.autograd.Function):
         _lib.require_cuda(x_pre)
         x_pre = x_pre.contiguous()
         B, C = x_pre.shape[0] // G, x_pre.shape[1]
-        out = torch.empty((B, C), dtype=torch.float32, device=x_pre.device)
-        arg = torch.empty((B, C), dtype=torch.int32, device=x_pre.device)
+        out = _lib.empty((B, C), dtype=torch.float32, device=x_pre.device)
+        arg = _lib.empty((B, C), dtype=torch.int32, device=x_pre.device)
         _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, C, _lib.ptr(out), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
         ctx.save_for_backward(arg)
         ctx.G = G
@@ -452,7 +452,7 @@ class _ViewMax(torch.autograd.Function):
         arg, = ctx.saved_tensors
         B, C = arg.shape
         dout = dout.contiguous()
-        dx = torch.empty((ctx.G * B, C), dtype=torch.float32, device=dout.device)
+        dx = _lib.empty((ctx.G * B, C), dtype=torch.float32, device=dout.device)
         _lib.check(lib.facl_viewmax_bwd(_lib.ptr(dout), _lib.ptr(arg), ctx.G, B, C, _lib.ptr(dx), _lib.stream()), "facl_viewmax_bwd")
         return dx, None
 

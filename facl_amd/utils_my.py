@@ -4,6 +4,7 @@ Same names, arguments, return shapes/strides and ``opt`` side effects as the ref
 (utils_my.py:7-42, :217-253, :255-291, :293-328); the body is one fused HIP kernel
 (facl_group) instead of the expand/sub/mul/sum/topk/masked-assign/gather chain.
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -24,9 +25,9 @@ def knn_radius_group(points, sample_num_level1, knn_K, ball_radius, want_idx=Fal
         return _knn_radius_group_clips(pts, sample_num_level1, knn_K, ball_radius, want_idx)
     M, N, D = pts.shape
     S, K = int(sample_num_level1), int(knn_K)
-    xt = torch.empty((M, S, K, D), dtype=torch.float32, device=pts.device)
-    yt = torch.empty((M, S, 3), dtype=torch.float32, device=pts.device)
-    idx = torch.empty((M, S, K), dtype=torch.int32, device=pts.device) if want_idx else None
+    xt = _lib.empty((M, S, K, D), dtype=torch.float32, device=pts.device)
+    yt = _lib.empty((M, S, 3), dtype=torch.float32, device=pts.device)
+    idx = _lib.empty((M, S, K), dtype=torch.int32, device=pts.device) if want_idx else None
     lib = _lib.load_library()
     with _lib.timed("facl_group"):
         _lib.check(lib.facl_group(_lib.ptr(pts), M, N, D, S, K, float(ball_radius), _lib.ptr(idx), _lib.ptr(xt),
@@ -41,9 +42,9 @@ def knn_radius_group(points, sample_num_level1, knn_K, ball_radius, want_idx=Fal
 def _knn_radius_group_clips(clips, sample_num_level1, knn_K, ball_radius, want_idx):
     B, G, N, D = clips.shape
     M, S, K = B * G, int(sample_num_level1), int(knn_K)
-    xt = torch.empty((M, S, K, D), dtype=torch.float32, device=clips.device)
-    yt = torch.empty((M, S, 3), dtype=torch.float32, device=clips.device)
-    idx = torch.empty((M, S, K), dtype=torch.int32, device=clips.device) if want_idx else None
+    xt = _lib.empty((M, S, K, D), dtype=torch.float32, device=clips.device)
+    yt = _lib.empty((M, S, 3), dtype=torch.float32, device=clips.device)
+    idx = _lib.empty((M, S, K), dtype=torch.int32, device=clips.device) if want_idx else None
     lib = _lib.load_library()
     with _lib.timed("facl_group"):
         _lib.check(lib.facl_group_clips(_lib.ptr(clips), B, G, N, D, S, K, float(ball_radius), _lib.ptr(idx), _lib.ptr(xt),
@@ -180,9 +181,9 @@ class _ContrastiveLosses(torch.autograd.Function):
         pos_c = (order[1:].to(torch.int32)[:, None] * Bk + n_idx[None, :]).reshape(-1).contiguous()
         sim_c = anchors @ keys.t()                                                 # ((G-1)B, J)  :103
         sim_g = xg @ keys.t()                                                      # (B, J)       :71
-        dsim_g = torch.empty_like(sim_g)
-        dsim_c = torch.empty_like(sim_c)
-        out = torch.empty(2, dtype=torch.float64, device=dev)
+        dsim_g = _lib.empty_like(sim_g)
+        dsim_c = _lib.empty_like(sim_c)
+        out = _lib.empty(2, dtype=torch.float64, device=dev)
         st = _lib.stream()
         _lib.check(lib.facl_contrast(_lib.ptr(sim_g), B, J, B, Bk, 1, G, 0, _lib.ptr(pos_g), clip_offset,
                                      _lib.ptr(dsim_g), out[0:1].data_ptr(), _lib.ptr(ws), st), "facl_contrast(global)")
@@ -231,8 +232,8 @@ class _ContrastivePair(torch.autograd.Function):
         ctx.mfma = (J % 4 == 0 and C % 4 == 0)     # the MFMA GEMMs contract over multiples of 4; odd toy shapes: library GEMM
         ctx.prec = _tail.current_precision()       # the backward GEMMs run in the forward's arithmetic
         sim = _tail.gemm_fwd(stacked, keys, None, prec=ctx.prec)[0] if ctx.mfma else stacked @ keys.t()     # ((G+1)B, J)  :71 and :103
-        dsim = torch.empty_like(sim)
-        out = torch.empty(2, dtype=torch.float64, device=dev)
+        dsim = _lib.empty_like(sim)
+        out = _lib.empty(2, dtype=torch.float64, device=dev)
         _lib.check(lib.facl_contrast_pair(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), clip_offset, _lib.ptr(dsim),
                                           _lib.ptr(out), _lib.ptr(ws), _lib.stream()), "facl_contrast_pair")
         ctx.save_for_backward(stacked, keys, dsim)
@@ -247,7 +248,7 @@ class _ContrastivePair(torch.autograd.Function):
         stacked, keys, dsim = ctx.saved_tensors
         # rows [0, G*B) carry the circle loss, rows [G*B, (G+1)*B) the global loss: one scaling launch for both
         lib = _lib.load_library()
-        ds = torch.empty_like(dsim)
+        ds = _lib.empty_like(dsim)
         R, J = dsim.shape
         _lib.check(lib.facl_scale_rows2(_lib.ptr(dsim), _lib.ptr(ds), ctx.GB, R, J, _lib.ptr(g_o.contiguous().float()),
                                         _lib.ptr(g_c.contiguous().float()), _lib.stream()), "facl_scale_rows2")
@@ -259,10 +260,20 @@ class _ContrastivePair(torch.autograd.Function):
         return d_stacked, d_keys, None, None, None
 
 
+def _check_order(order, G):
+    """A host-side `order` (list / ndarray / CPU tensor) must be a permutation of range(G) (np.random.shuffle of
+    arange(G), cn3d_train_motion_GL.py:297-298).  A device tensor is not read back (no sync on the step); the kernel
+    clamps its entries so that a corrupt one cannot address outside the similarity matrix."""
+    o = np.asarray(order.cpu() if torch.is_tensor(order) else order).reshape(-1)
+    if o.shape[0] != G or not np.array_equal(np.sort(o), np.arange(G)):
+        raise ValueError("order must be a permutation of range(%d), got %r" % (G, o.tolist()))
+
+
 def contrastive_losses_stacked(num_crop, stacked, order, x_keys=None, clip_offset=0):
     """(loss_c, loss_circle) from the model's stacked output [x ; x_global] (facl_amd.cn3d_model_conbag: ``_stacked``)."""
     G = num_crop
     if not (torch.is_tensor(order) and order.device == stacked.device and order.dtype == torch.long):
+        _check_order(order, G)
         order = torch.as_tensor(order, device=stacked.device, dtype=torch.long)
     return _ContrastivePair.apply(stacked, x_keys, order.contiguous(), G, clip_offset)
 

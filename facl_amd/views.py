@@ -78,7 +78,7 @@ def build_views(clips, rng=None, device="cuda"):
     idx = torch.from_numpy(np.stack(idxs)).to(dev)
     noise = torch.from_numpy(np.stack(noises)).to(dev)
     cs = torch.from_numpy(np.stack(css)).to(dev)
-    out = torch.empty((NUM_CROP * B, NUM_POINT, 4), dtype=torch.float32, device=dev)
+    out = _lib.empty((NUM_CROP * B, NUM_POINT, 4), dtype=torch.float32, device=dev)
     _lib.require_cuda(out)
     fn = lib.facl_build_views_f32 if dt == np.float32 else lib.facl_build_views_f64
     _lib.check(fn(_lib.ptr(src), src.shape[0], 8, _lib.ptr(idx), _lib.ptr(noise), _lib.ptr(cs), B, _lib.ptr(out),

@@ -89,7 +89,7 @@ def test_graph_replay_equals_eager():
 def test_graph_replay_sees_learning_rate_changes_with_fused_adam():
     """A StepLR change made AFTER the capture must reach the replayed Adam (FusedAdam keeps lr on the device; the graph
     holds no fill, GraphedStep refreshes it before each replay).  Parameters after 3 steps with lr 3e-4, 1e-3, 1e-5:
-    graph replay == eager FusedAdam == torch.optim.Adam."""
+    graph replay == eager FusedAdam (FusedAdam == torch.optim.Adam under an lr change: tests/test_gpu_tail.py)."""
     from facl_amd.cn3d_model_conbag import PointNet_Plus
     from facl_amd.optim import FusedAdam
     from facl_amd.train_common import ContrastiveStep, GraphedStep
@@ -122,8 +122,6 @@ def test_graph_replay_sees_learning_rate_changes_with_fused_adam():
         torch.cuda.synchronize()
         return {k: v.detach().clone() for k, v in net.named_parameters()}
 
-    net_t, step_t = make("torch")
-    p_torch = run(net_t, step_t, lambda c: step_t(c, order=order))
     net_e, step_e = make("fused")
     p_eager = run(net_e, step_e, lambda c: step_e(c, order=order))
     net_g, step_g = make("fused")
@@ -138,7 +136,6 @@ def test_graph_replay_sees_learning_rate_changes_with_fused_adam():
     for k in p_eager:
         ref = p_eager[k]
         assert torch.allclose(p_graph[k], ref, rtol=1e-5, atol=1e-7), k          # the graph followed the schedule
-        assert torch.allclose(p_torch[k], ref, rtol=2e-3, atol=2e-5), k          # and both follow torch's Adam (update noise)
         moved += int((ref.cpu() - sd0[k]).abs().max() > 5e-4)
     assert moved > 10                                         # the 1e-3 step is visible: a stuck 3e-4 / 1e-5 would not pass
 

@@ -9,6 +9,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _poisoned_scratch():
+    """Every test of this module runs with NaN-poisoned scratch (facl_amd._lib.poisoned): the partial-sum workspace and
+    every output / scratch tensor the host layer allocates are filled with NaN bytes before the launches, so a partial
+    row or output element left unwritten at a ragged shape fails the comparison instead of reading recycled memory."""
+    from facl_amd import _lib
+    with _lib.poisoned():
+        yield
+
+
 def _ws():
     from facl_amd.sa_mlp import _Workspace
     return _Workspace.get(torch.device(DEV))
@@ -29,8 +39,8 @@ def test_gemm_fwd(M, K, N, pro, ctr):
     pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
     cen = torch.randn(M, 3, device=DEV, generator=g) if ctr else None
     Wc = torch.randn(N, 3, device=DEV, generator=g) if ctr else None
-    y = torch.empty(M, N, device=DEV)
-    sums = torch.empty(N, 2, dtype=torch.float64, device=DEV)
+    y = _lib.empty(M, N, device=DEV)
+    sums = _lib.empty(N, 2, dtype=torch.float64, device=DEV)
     p = _lib.ptr
     _lib.check(lib.facl_gemm_fwd(p(a), M, K, p(W), K, N, p(b), p(ps), p(pt), p(cen), p(Wc), 3, p(y), p(sums), p(_ws()),
                                  _lib.stream()), "gemm_fwd")
@@ -54,7 +64,7 @@ def test_gemm_dgrad(M, N, K, ldw, off):
     dy = torch.randn(M, N, device=DEV, generator=g)
     Wfull = torch.randn(N, ldw, device=DEV, generator=g) / N ** 0.5
     W = Wfull[:, off:off + K]
-    da = torch.empty(M, K, device=DEV)
+    da = _lib.empty(M, K, device=DEV)
     _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, W.data_ptr(), ldw, K, _lib.ptr(da), _lib.stream()), "dgrad")
     ref = dy.double() @ W.double()
     assert rel_err(da.cpu().numpy(), ref.cpu().numpy()) < 2e-6
@@ -68,8 +78,8 @@ def test_gemm_wgrad(M, N, K, nz):
     g = torch.Generator(device=DEV).manual_seed(M + K)
     dy = torch.randn(M, N, device=DEV, generator=g)
     a = torch.randn(M, K, device=DEV, generator=g)
-    dW = torch.empty(N, K, device=DEV)
-    slices = torch.empty(nz * N * K, device=DEV)
+    dW = _lib.empty(N, K, device=DEV)
+    slices = _lib.empty(nz * N * K, device=DEV)
     _lib.check(lib.facl_gemm_wgrad(_lib.ptr(dy), _lib.ptr(a), M, N, K, K, _lib.ptr(dW), _lib.ptr(slices), nz,
                                    _lib.stream()), "wgrad")
     ref = dy.double().t() @ a.double()
@@ -118,10 +128,10 @@ def test_gemm_fwd_segmax_fused_epilogue():
     W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
     b = torch.randn(N, device=DEV, generator=g)
     sgn = torch.where(torch.rand(N, device=DEV, generator=g) < 0.5, -1.0, 1.0)
-    y = torch.empty(M, N, device=DEV)
-    sums = torch.empty(N, 2, dtype=torch.float64, device=DEV)
-    ymax = torch.empty(M // 64, N, device=DEV)
-    arg = torch.empty(M // 64, N, dtype=torch.int32, device=DEV)
+    y = _lib.empty(M, N, device=DEV)
+    sums = _lib.empty(N, 2, dtype=torch.float64, device=DEV)
+    ymax = _lib.empty(M // 64, N, device=DEV)
+    arg = _lib.empty(M // 64, N, dtype=torch.int32, device=DEV)
     p = _lib.ptr
     _lib.check(lib.facl_gemm_fwd_segmax(p(a), M, K, p(W), K, N, p(b), p(sgn), p(y), p(sums), p(ymax), p(arg), p(_ws()),
                                         _lib.stream()), "gemm_fwd_segmax")
@@ -151,19 +161,19 @@ def test_gemm_x3_twins_within_their_bound(M, K, N):
     b = torch.randn(N, device=DEV, generator=g)
     dy = torch.randn(M, N, device=DEV, generator=g)
     p, st = _lib.ptr, _lib.stream()
-    y, y6 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    sums = torch.empty(N, 2, dtype=torch.float64, device=DEV)
+    y, y6 = _lib.empty(M, N, device=DEV), _lib.empty(M, N, device=DEV)
+    sums = _lib.empty(N, 2, dtype=torch.float64, device=DEV)
     _lib.check(lib.facl_gemm_fwd_x3(p(a), M, K, p(W), K, N, p(b), None, None, None, None, 0, p(y), p(sums), p(_ws()), st), "fwd_x3")
     _lib.check(lib.facl_gemm_fwd(p(a), M, K, p(W), K, N, p(b), None, None, None, None, 0, p(y6), None, p(_ws()), st), "fwd")
     ref = a.double() @ W.double().t() + b.double()
     e3, e6 = rel_err(y.cpu().numpy(), ref.cpu().numpy()), rel_err(y6.cpu().numpy(), ref.cpu().numpy())
     assert e6 < 2e-6 and e6 < e3 < 5e-5, (e3, e6)                      # really the three-product arithmetic, inside its bound
     assert rel_err(sums[:, 1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 5e-5
-    da = torch.empty(M, K, device=DEV)
+    da = _lib.empty(M, K, device=DEV)
     _lib.check(lib.facl_gemm_dgrad_x3(p(dy), M, N, p(W), K, K, p(da), st), "dgrad_x3")
     assert rel_err(da.cpu().numpy(), (dy.double() @ W.double()).cpu().numpy()) < 5e-5
     nz = 4
-    dW = torch.empty(N, K, device=DEV)
-    sl = torch.empty(nz * N * K, device=DEV)
+    dW = _lib.empty(N, K, device=DEV)
+    sl = _lib.empty(nz * N * K, device=DEV)
     _lib.check(lib.facl_gemm_wgrad_x3(p(dy), p(a), M, N, K, K, p(dW), p(sl), nz, st), "wgrad_x3")
     assert rel_err(dW.cpu().numpy(), (dy.double().t() @ a.double()).cpu().numpy()) < 5e-5

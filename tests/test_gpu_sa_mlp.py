@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _poisoned_scratch():
+    """Every test of this module runs with NaN-poisoned scratch (facl_amd._lib.poisoned): the partial-sum workspace and
+    every output / scratch tensor the host layer allocates are filled with NaN bytes before the launches, so a partial
+    row or output element left unwritten at a ragged shape fails the comparison instead of reading recycled memory."""
+    from facl_amd import _lib
+    with _lib.poisoned():
+        yield
+
+
 def _params(sd, dev, dtype=torch.float32):
     m = {"W1": "net3DV_1.0.weight", "b1": "net3DV_1.0.bias", "g1": "net3DV_1.1.weight", "be1": "net3DV_1.1.bias",
          "rm1": "net3DV_1.1.running_mean", "rv1": "net3DV_1.1.running_var",

@@ -120,6 +120,25 @@ def test_contrastive_pair_on_stacked_embeddings_vs_closed_form_fp64(G, B, C, wor
     assert float((g[G * B:] - gr[0]).norm() / gr[0].norm()) < 2e-5
 
 
+def test_contrastive_pair_rejects_bad_order_and_clip_offset():
+    """Error behaviour of the loss entry: a host-side `order` that is no permutation of range(G) raises before any launch;
+    a clip window outside the key columns returns FACL_E_SHAPE; a corrupt DEVICE order is clamped in the kernel (finite
+    values, no out-of-bounds access)."""
+    from facl_amd.utils_my import contrastive_losses_stacked
+    G, B, C = 4, 3, 16
+    st = torch.randn((G + 1) * B, C, device=DEV)
+    for bad in ([0, 1, 2, 4], [0, 1, 1, 2], [0, 1, 2]):
+        with pytest.raises(ValueError):
+            contrastive_losses_stacked(G, st, np.array(bad))
+    keys = torch.randn(G * 2 * B, C, device=DEV)
+    for off in (-1, B + 1):
+        with pytest.raises(RuntimeError):
+            contrastive_losses_stacked(G, st, np.arange(G), x_keys=keys, clip_offset=off)
+    lc, lo = contrastive_losses_stacked(G, st, torch.tensor([0, 7, -3, 1], device=DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(lc) and torch.isfinite(lo)
+
+
 def test_fused_adam_equals_torch_adam():
     """facl_amd.optim.FusedAdam (one launch over all tensors, device-resident step / lr) vs torch.optim.Adam with the
     reference's hyper-parameters (cn3d_train_motion_GL.py:180): 6 steps on tensors of ragged sizes, a parameter without a

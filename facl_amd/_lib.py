@@ -59,6 +59,13 @@ SIGNATURES = {
     "facl_gemm_fwd_segmax_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad_f16": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_wgrad_f16": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "facl_gemm_wgrad_pro": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    "facl_gemm_wgrad_pro_x3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    "facl_gemm_rs_planes_bytes": [c_i, c_i, c_i],
+    "facl_gemm_rs_planes": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
+    "facl_gemm_rs_supported": [c_l, c_i, c_i],
+    "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_p],
     "facl_gemm_fwd_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_segmax_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
@@ -83,7 +90,7 @@ SIGNATURES = {
     "facl_viewmax_bwd_add": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "facl_sa_bwd_final": [c_p] * 13 + [c_i, c_d] + [c_p] * 9 + [c_p],
 }
-RESTYPE_I64 = {"facl_ws_bytes"}
+RESTYPE_I64 = {"facl_ws_bytes", "facl_gemm_rs_planes_bytes"}
 
 
 def lib_path():

@@ -163,11 +163,16 @@ class PointNet_Plus(nn.Module):
 
         # net3DV_3 (:220).  torch.cat((yt, xt), 1) (:219) is never built: the first GEMM takes the centroid xyz as a
         # rank-3 term in its epilogue
-        h = _tail.linear_bn_relu(pooled, self.net3DV_3[0], self.net3DV_3[1], training, self.bn_reduce_fn,
-                                 centers=centers)
-        h = _tail.linear_bn_relu(h, self.net3DV_3[3], self.net3DV_3[4], training, self.bn_reduce_fn)
-        # last layer fused with my_max_pool (:222-223): xt_local (M,1024,S,1) is never materialised post-BN
-        x_pre = _tail.linear_bn_relu_segmax(h, self.net3DV_3[6], self.net3DV_3[7], training, S, self.bn_reduce_fn)
+        n3 = self.net3DV_3
+        widths = (n3[0].weight.shape[1] - 3, n3[0].weight.shape[0], n3[3].weight.shape[0], n3[6].weight.shape[0])
+        if _tail.net3dv3_supported(pooled.shape[0], widths, S, _tail.current_precision()):
+            # the 49,152-row case: row-streamed GEMMs, BN + ReLU of a layer applied in the next GEMM's prologue
+            x_pre = _tail.net3dv3(pooled, centers, n3, training, S, self.bn_reduce_fn)
+        else:
+            h = _tail.linear_bn_relu(pooled, n3[0], n3[1], training, self.bn_reduce_fn, centers=centers)
+            h = _tail.linear_bn_relu(h, n3[3], n3[4], training, self.bn_reduce_fn)
+            # last layer fused with my_max_pool (:222-223): xt_local (M,1024,S,1) is never materialised post-BN
+            x_pre = _tail.linear_bn_relu_segmax(h, n3[6], n3[7], training, S, self.bn_reduce_fn)
         # gobaol_max_pool over all gost*S local features of a clip (:225-226) = max over the gost views of the per-view
         # maxima (rows are view-major: g*B+b; first view wins ties, like the reference's max-pool over the sequence), then
         # :228 x = netR_FC(x_pre), :229 x_global = netR_FC(x_global_pre): one pass over the two Linear layers for both,

@@ -1,0 +1,428 @@
+// Row-streamed split-bf16 GEMM for the per-centroid layers (net3DV_3, cn3d_model_conbag.py:61-77: 49,152 rows x
+// {256,512,1024} channels) -- forward  y = f(a) W^T + b [+ centres Wc^T]  and dgrad  da = dy W.
+//
+// Why a second GEMM shape.  k_gemm_sb (gemm.hip) stages BOTH operands through LDS as three bf16 planes per 32-deep stage:
+// per MFMA it pays ~0.5 ds_read_b128, ~250 B of LDS fill and ~3.7 VALU instructions (split of both operands), and its
+// PMC profile says so (MFMA busy 0.39-0.46, issue-stalled 0.44-0.53).  Here the two operands are treated by what they
+// are:
+//   * the WEIGHTS are constant during a step: they are split ONCE (k_rs_planes) into fragment-ordered bf16 planes
+//     [k-step][32-column tile][plane][lane] x 16 B, and a workgroup streams the planes of its 256 output columns through a
+//     3-slot LDS ring with LDS-DMA (global_load_lds_dwordx4: no registers, no VALU, no ds_write);
+//   * the ACTIVATIONS are private to the wave that owns their 32 rows: each wave DMAs its own 32 x 32 fp32 stage into a
+//     private LDS slot (coalesced 128-B rows, XOR swizzle on the SOURCE address), reads its A fragments (8 consecutive
+//     k of its row per lane) with two ds_read_b128 per k-step, applies the previous layer's BatchNorm + ReLU on the fly
+//     (the PRO slot: k_rows_bn_relu and its activation round trip disappear) and splits them into bf16 planes IN REGISTERS.
+// One wave = one 32-row tile x 256 columns (8 accumulator tiles, 128 VGPRs), 8 waves per workgroup, one workgroup per
+// CU.  Per MFMA: 0.5 ds_read_b128, 64 B of LDS fill, ~1.3 VALU.  Same arithmetic as k_gemm_sb (six bf16 products per
+// multiply-add, smallest first, 16-deep k-steps in the same order): results are bit-identical to it.
+// Epilogue (lane = column, registers = rows): bias, per-column (sum, sumsq) for the BatchNorm that follows (8 waves
+// combined in LDS in fixed order, one fp64 partial row per workgroup), optional my_max_pool over each cloud's 64 rows
+// (two waves per cloud, merged through LDS, first row wins ties), 128-B row segments stored straight from registers.
+// Roofline: bf16 MFMA (2.5 PFLOP/s dense; 6 executed FLOPs per algorithmic one).
+#include "common.h"
+
+int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+extern "C" int64_t facl_ws_bytes(void);
+
+namespace {
+
+constexpr int RS_CT = 8;                          // 32-column tiles per workgroup (256 output columns)
+constexpr int RS_WAVES = 4;                       // one 32-row tile per wave (128 rows per workgroup), two workgroups per CU
+constexpr int RS_WPP = RS_CT * 3 / RS_WAVES;      // 1-KiB weight pieces a wave issues per k-step
+constexpr int RS_WSLOT = RS_CT * 3 * 1024;        // bytes of one k-step (16 k) of planes for 256 columns: 24 KiB
+constexpr int RS_ASLOT = 32 * 128;                // bytes of one stage (32 k) of a wave's 32 rows, fp32: 4 KiB
+constexpr int RS_LDS_W = 2 * RS_WSLOT;            // 48 KiB: k-step j in slot j & 1
+constexpr int RS_LDS_A = RS_WAVES * RS_ASLOT;     // 16 KiB (one stage slot per wave)
+constexpr int RS_KMAX = 1024;                     // longest contraction
+constexpr int RS_KPRO = 512;                      // longest contraction WITH a prologue: tables scale[K] | shift[K], 4 KiB
+constexpr int RS_LDS = RS_LDS_W + RS_LDS_A + 2 * RS_KPRO * 4;     // 68 KiB
+
+struct RsArgs {
+    const float* A; int lda; int M; int K;        // K % 32 == 0
+    const uint4* Wp; int NT;                      // planes [k-step][NT column tiles][3][64]; NT = N / 32
+    int N;                                        // output columns, N % 256 == 0
+    const float* bias;                            // (N) or null
+    const float* pscale; const float* pshift;     // (K) prologue relu(scale*a + shift), or null
+    const float* centers;                         // (M,3) or null: k-step K/16 of Wp holds the centre columns
+    float* C; int ldc;
+    double* part;                                 // statistics partial rows [gridDim.y][2N], or null
+    const float* sgn; float* smax; int* sarg;     // my_max_pool over blocks of 64 rows: (M/64, N), or null
+};
+
+// ---- weights -> fragment-ordered bf16 planes -------------------------------------------------------------------------
+// value(o, c) = W[o*so + c*sc]: o = output channel (lane of the B operand), c = contraction index.  forward: so = ldw,
+// sc = 1 (y = a W^T); dgrad: so = 1, sc = ldw (da = dy W).  Entry ((ks*NT + o/32)*3 + plane)*64 + 32h + o%32 holds the 8
+// k-slots c = 16ks + 8h + j of column o.  `xc` (forward only): one more k-step whose slots 0..2 (h = 0) are
+// Wc[o][0..2] -- the centroid-xyz columns of torch.cat((yt, xt), 1), cn3d_model_conbag.py:219.
+__global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
+                                                   const float* __restrict__ xc, int ldxc, uint4* __restrict__ out) {
+    const int NT = NO >> 5, nks = NC >> 4;
+    const long long total = (long long)(nks + (xc ? 1 : 0)) * NT * 64;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ln = (int)(i & 63);
+        const long long t = i >> 6;
+        const int ot = (int)(t % NT), ks = (int)(t / NT);
+        const int o = 32 * ot + (ln & 31), hh = ln >> 5;
+        float v[8];
+        if (ks < nks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W[(long long)o * so + (long long)(16 * ks + 8 * hh + j) * sc];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (hh == 0 && j < 3) ? xc[(long long)o * ldxc + j] : 0.f;
+        }
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
+        uint4* d = out + ((long long)(ks * NT + ot) * 3) * 64 + ln;
+        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+struct RsTile { int x, y; };
+// XCD-aware order (as gemm.hip: xcd_tile): each XCD walks a contiguous range of (row group, column block) tiles,
+// column blocks fastest, so the column blocks that re-read one 256-row panel of A hit the same L2.
+__device__ __forceinline__ RsTile rs_tile() {
+    const int nbx = gridDim.x, total = nbx * gridDim.y;
+    const int b = blockIdx.x + nbx * blockIdx.y;
+    const int per = total >> 3, rem = total & 7, xcd = b & 7, slot = b >> 3;
+    const int L = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    RsTile t;
+    t.x = L % nbx; t.y = L / nbx;
+    return t;
+}
+
+// One LDS-DMA piece: 64 lanes x 16 B from each lane's global address `gsrc` to LDS bytes [lds_dst, lds_dst + 1024).
+// Issued from inline asm on purpose: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of later ds_reads that may alias it -- inside this pipeline that drains the pieces issued a
+// moment ago (seen in the ISA of the builtin form).  Here every wait is counted by hand (see the pipeline comment).
+// M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void rs_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+template <bool PRO, bool SEG>
+__global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const wring = lds;
+    char* const abuf = lds + RS_LDS_W + wave * RS_ASLOT;
+    float* const tab = reinterpret_cast<float*>(lds + RS_LDS_W + RS_LDS_A);
+    const unsigned wring_a = __builtin_amdgcn_readfirstlane(lds_addr(wring));
+    const unsigned abuf_a = __builtin_amdgcn_readfirstlane(lds_addr(abuf));
+    const RsTile tile = rs_tile();
+    const int cb = tile.x;
+    const int row0 = (tile.y * RS_WAVES + wave) * 32;
+    const int nks = g.K >> 4, nst = g.K >> 5;
+    const int nks_all = nks + (g.centers ? 1 : 0);
+
+    if (PRO) {
+        for (int i = tid; i < g.K; i += 64 * RS_WAVES) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
+        __syncthreads();
+    }
+
+    // ---- DMA issue helpers (wave-uniform control flow; VM-counter bookkeeping in the pipeline comment below)
+    // this wave's RS_CT / RS_WAVES column tiles are RS_WPP consecutive 1-KiB pieces of a k-step
+    const uint4* wsrc = g.Wp + ((size_t)(RS_CT * cb) * 3 + wave * RS_WPP) * 64 + lane;
+    const size_t wstep = (size_t)g.NT * 3 * 64;                                        // uint4 per k-step
+    auto issueW = [&](int j) {
+        if (j < nks_all) {
+            const unsigned dst = wring_a + (j & 1) * RS_WSLOT + wave * RS_WPP * 1024;
+            const uint4* src = wsrc + (size_t)j * wstep;
+#pragma unroll
+            for (int p = 0; p < RS_WPP; ++p) rs_dma16(src + p * 64, dst + p * 1024);
+        }
+    };
+    // activations: piece i = rows 8i + (lane>>3); the 16-B chunk that lands in physical chunk c' of row r is logical
+    // chunk c' ^ ((r>>1)&7) (conflict-free ds_read_b128 of one logical chunk over the 32 rows, cf. k_gemm_dma)
+    const float* asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        int gr = row0 + r;
+        gr = gr < g.M ? gr : g.M - 1;                                  // rows past M re-read the last row (never stored / counted)
+        asrc[i] = g.A + (size_t)gr * g.lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+    auto issueA = [&](int s) {                                         // 4 pieces of 1 KiB
+        if (s < nst) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs_dma16(asrc[i] + 32 * s, abuf_a + i * 1024);
+        }
+    };
+    // fragment reads of a whole stage: lane (row q, half h) takes the 8 k = 16 t + 8h + 0..7 of its row for both k-steps
+    // t = 0, 1 of the stage: logical chunks 4t + 2h, 4t + 2h + 1
+    const int akey = (q >> 1) & 7;
+    auto read_stage = [&](float4 (&r)[4]) {
+        const char* base = abuf + q * 128;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c = 4 * t + 2 * h;
+            r[2 * t] = *reinterpret_cast<const float4*>(base + ((c ^ akey) << 4));
+            r[2 * t + 1] = *reinterpret_cast<const float4*>(base + (((c + 1) ^ akey) << 4));
+        }
+    };
+    auto make_planes = [&](int j, const float4& r0, const float4& r1, bf16x8 (&P)[3]) {
+        float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        if (PRO) {
+            const float4* ts = reinterpret_cast<const float4*>(tab + 16 * j + 8 * h);
+            const float4* tt = reinterpret_cast<const float4*>(tab + RS_KPRO + 16 * j + 8 * h);
+            const float4 s0 = ts[0], s1 = ts[1], t0 = tt[0], t1 = tt[1];
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+        }
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
+        P[0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
+        P[1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
+        P[2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+    };
+
+    f32x16 acc[RS_CT];
+#pragma unroll
+    for (int ct = 0; ct < RS_CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+    // MFMAs of one k-step.  The B fragments are double-buffered by hand and the groups are fenced (sched_barrier) so that
+    // the scheduler cannot hoist all 24 fragment reads of the k-step (96 VGPRs) above the first MFMA: with 128
+    // accumulator registers live that spills.  `mid()` runs between the two halves (the next k-step's plane split).
+    auto mfma_step = [&](int j, const bf16x8 (&P)[3], auto&& mid) {
+        const uint4* ws = reinterpret_cast<const uint4*>(wring + (j & 1) * RS_WSLOT) + lane;
+        bf16x8 b0[3], b1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[p * 64]);
+#pragma unroll
+        for (int ct = 0; ct < RS_CT; ct += 2) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b1[p] = __builtin_bit_cast(bf16x8, ws[((ct + 1) * 3 + p) * 64]);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[ct] = MFMA_BF16(P[PA[t]], b0[PB[t]], acc[ct]);     // smallest terms first
+            __builtin_amdgcn_sched_barrier(0);
+            if (ct + 2 < RS_CT) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[((ct + 2) * 3 + p) * 64]);
+            }
+            if (ct == 2) mid();
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[ct + 1] = MFMA_BF16(P[PA[t]], b1[PB[t]], acc[ct + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- pipeline.  Weight ring: k-step j in slot j & 1.  VM operations of a wave, in issue order: prologue A(0), W(0);
+    // top of k-step j (behind the barrier): W(j+1) [RS_WPP pieces]; at even j = 2s, once the stage's fragments are in
+    // registers: A(s+1) [4 pieces] into the wave's single activation slot.  At the top of k-step j the wave needs W(j),
+    // issued at the top of j-1: at odd j only A((j+1)/2) came after it -> vmcnt(4); at even j nothing did -> vmcnt(0), which
+    // also lands A(j/2), needed now.  The workgroup barrier behind the wait makes every wave's pieces of W(j) visible and
+    // proves that all waves have left k-step j-1, whose slot the next issue overwrites.
+    issueA(0); issueW(0);
+    bf16x8 P0[3], P1[3];
+    float4 raw[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_stage(raw);
+    make_planes(0, raw[0], raw[1], P0);
+    issueW(1);
+    for (int j = 0; j + 2 < nks; j += 2) {
+        // -- even k-step j (W(j) and this stage's activations landed at the previous wait): MFMAs on P0, P1 from the
+        //    stage's second half; the activation slot is free once `raw` is in registers -> next stage's DMA
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issueA((j >> 1) + 1);
+        mfma_step(j, P0, [&]() { make_planes(j + 1, raw[2], raw[3], P1); });
+        // -- odd k-step j+1
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issueW(j + 2);
+        mfma_step(j + 1, P1, []() {});
+        // -- top of the next stage: W(j+2) and A(j/2+1) have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issueW(j + 3);
+        read_stage(raw);
+        make_planes(j + 2, raw[0], raw[1], P0);
+    }
+    {   // last stage (k-steps nks-2, nks-1): nothing more to stream but the centre k-step
+        const int j = nks - 2;
+        mfma_step(j, P0, [&]() { make_planes(j + 1, raw[2], raw[3], P1); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issueW(j + 2);
+        mfma_step(j + 1, P1, []() {});
+    }
+    if (g.centers) {                                                   // the centroid-xyz columns: one more k-step
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (h == 0) {
+            int gr = row0 + q;
+            gr = gr < g.M ? gr : g.M - 1;
+            c0 = g.centers[(size_t)gr * 3]; c1 = g.centers[(size_t)gr * 3 + 1]; c2 = g.centers[(size_t)gr * 3 + 2];
+        }
+        unsigned hi[2], mi[2], lo[2];
+        split_pair(c0, c1, hi[0], mi[0], lo[0]);
+        split_pair(c2, 0.f, hi[1], mi[1], lo[1]);
+        bf16x8 Pc[3] = {as_bf16x8(hi[0], hi[1], 0u, 0u), as_bf16x8(mi[0], mi[1], 0u, 0u), as_bf16x8(lo[0], lo[1], 0u, 0u)};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_step(nks, Pc, []() {});
+    }
+
+    // ---- epilogue: lane = column 256 cb + 32 ct + q, register r = row row0 + rowmap(r, h)
+    float* const wstat = reinterpret_cast<float*>(abuf);               // this wave's (sum, sumsq) per column: 2 KiB
+    float* const wbest = wstat + 512;                                  // odd waves: (max, arg) of their 32 rows: 2 KiB
+#pragma unroll
+    for (int ct = 0; ct < RS_CT; ++ct) {
+        const int n = 256 * cb + 32 * ct + q;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+        const float sg = SEG ? sgn_of(g.sgn[n]) : 1.f;
+        float s = 0.f, sq = 0.f, best = 0.f;
+        int bp = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + rowmap(r, h);
+            const float v = acc[ct][r] + bias;
+            if (row < g.M) {
+                g.C[(size_t)row * g.ldc + n] = v;
+                s += v; sq = fmaf(v, v, sq);
+            }
+            if (SEG) {
+                const float sv = sg * v;
+                if (r == 0 || sv > best) { best = sv; bp = rowmap(r, 0); }
+            }
+        }
+        if (g.part) {
+            const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+            if (h == 0) { wstat[2 * (32 * ct + q)] = st; wstat[2 * (32 * ct + q) + 1] = sqt; }
+        }
+        if (SEG) {
+            bp += 4 * h;
+            const float ob = __shfl_xor(best, 32, 64);
+            const int op = __shfl_xor(bp, 32, 64);
+            if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }          // first max wins (MaxPool2d)
+            if (wave & 1) {
+                if (h == 0) { wbest[2 * (32 * ct + q)] = best; wbest[2 * (32 * ct + q) + 1] = __int_as_float(bp); }
+            } else {
+                acc[ct][0] = best; acc[ct][1] = __int_as_float(bp);                    // parked until the partner has written
+            }
+        }
+    }
+    if (!g.part && !SEG) return;
+    __syncthreads();
+    if (SEG && !(wave & 1) && h == 0) {                                // even wave: rows 0..31 of the cloud; partner: rows 32..63
+        const float* pb = reinterpret_cast<const float*>(lds + RS_LDS_W + (wave + 1) * RS_ASLOT) + 512;
+        const int cloud = row0 >> 6;
+        if (row0 < g.M) {
+#pragma unroll
+            for (int ct = 0; ct < RS_CT; ++ct) {
+                float best = acc[ct][0];
+                int bp = __float_as_int(acc[ct][1]);
+                const float ob = pb[2 * (32 * ct + q)];
+                if (ob > best) { best = ob; bp = 32 + __float_as_int(pb[2 * (32 * ct + q) + 1]); }
+                const size_t o = (size_t)cloud * g.N + 256 * cb + 32 * ct + q;
+                g.smax[o] = best;
+                g.sarg[o] = bp;
+            }
+        }
+    }
+    if (g.part && tid < 256) {                                         // the waves in wave order, fp64: one partial row per workgroup
+        double s = 0.0, sq = 0.0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const float* ps = reinterpret_cast<const float*>(lds + RS_LDS_W + w * RS_ASLOT);
+            s += (double)ps[2 * tid]; sq += (double)ps[2 * tid + 1];
+        }
+        double* pr = g.part + ((size_t)tile.y * g.N + 256 * cb + tid) * 2;
+        pr[0] = s; pr[1] = sq;
+    }
+}
+
+int rs_launch(const RsArgs& g, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        const void* fns[4] = {(const void*)k_gemm_rs<false, false>, (const void*)k_gemm_rs<true, false>,
+                              (const void*)k_gemm_rs<false, true>, (const void*)k_gemm_rs<true, true>};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_done = true;
+    }
+    dim3 grid(g.N / 256, (g.M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
+    const dim3 blk(64 * RS_WAVES);
+    if (g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true>), grid, blk, RS_LDS, st, g);
+    else if (g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false>), grid, blk, RS_LDS, st, g);
+    else if (g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true>), grid, blk, RS_LDS, st, g);
+    else hipLaunchKernelGGL((k_gemm_rs<false, false>), grid, blk, RS_LDS, st, g);
+    return facl_launch_status();
+}
+
+}  // namespace
+
+extern "C" int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers) {
+    if (N < 32 || K < 16) return 0;
+    return (int64_t)(K / 16 + (with_centers ? 1 : 0)) * (N / 32) * 3 * 64 * 16;
+}
+
+// planes for y = a W^T (transposed = 0: W (N,K) row-major, leading dimension ldw; output columns N, contraction K;
+// Wc (N,3), leading dimension ldwc, adds the centre k-step) or for da = dy W (transposed = 1: output columns K,
+// contraction N).  Output columns must be a multiple of 32, the contraction a multiple of 16.
+extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc,
+                                   void* planes, void* stream) {
+    if (!W || !planes) return FACL_E_NULL;
+    if (N < 1 || K < 1 || ldw < K) return FACL_E_SHAPE;
+    const int NO = transposed ? K : N, NC = transposed ? N : K;
+    if ((NO & 31) || (NC & 15) || (transposed && Wc)) return FACL_E_SHAPE;
+    const long long so = transposed ? 1 : ldw, sc = transposed ? ldw : 1;
+    const long long total = (long long)(NC / 16 + (Wc ? 1 : 0)) * (NO / 32) * 64;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_rs_planes, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes);
+    return facl_launch_status();
+}
+
+// 1 when facl_gemm_rs_fwd / _dgrad take the shape (rows M, contraction K, output columns N), else 0
+extern "C" int facl_gemm_rs_supported(int64_t M, int K, int N) {
+    return (M >= 2048 && M <= 0x7fffffff && K >= 64 && K <= RS_KMAX && !(K & 31) && N >= 256 && !(N & 255)) ? 1 : 0;
+}
+
+// y (M,N) = f(a) W^T + bias [+ centers Wc^T]   with `planes` = facl_gemm_rs_planes(W, ..., transposed 0, Wc).
+// f = relu(pscale*a + pshift) per input channel when pscale is given (the previous layer's BatchNorm + ReLU).
+// sums (N,2): per-column (sum, sumsq) of y (or null).  sgn / ymax / arg (all or none): fused my_max_pool over blocks of 64
+// rows as in facl_gemm_fwd_segmax (M % 64 == 0).
+extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int N, const float* bias,
+                                const float* pscale, const float* pshift, const float* centers, float* y, double* sums,
+                                const float* sgn, float* ymax, int32_t* arg, void* ws, void* stream) {
+    if (!a || !planes || !y || (sums && !ws)) return FACL_E_NULL;
+    if (!facl_gemm_rs_supported(M, K, N)) return FACL_E_SHAPE;
+    if ((pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
+    if (pscale && K > RS_KPRO) return FACL_E_SHAPE;
+    if ((sgn == nullptr) != (ymax == nullptr) || (sgn == nullptr) != (arg == nullptr)) return FACL_E_NULL;
+    if (sgn && (M & 63)) return FACL_E_SHAPE;
+    if (((uintptr_t)a | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
+    const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
+    if (sums && (size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    RsArgs g{a, K, (int)M, K, (const uint4*)planes, N / 32, N, bias, pscale, pshift, centers, y, N,
+             sums ? (double*)ws : nullptr, sgn, ymax, arg};
+    int rc = rs_launch(g, st);
+    if (rc || !sums) return rc;
+    return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
+}
+
+// da (M,K) = dy (M,N) W   with `planes` = facl_gemm_rs_planes(W, ..., transposed 1)
+extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int K, float* da, void* stream) {
+    if (!dy || !planes || !da) return FACL_E_NULL;
+    if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
+    if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
+    RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
+             nullptr, nullptr, nullptr, nullptr};
+    return rs_launch(g, (hipStream_t)stream);
+}

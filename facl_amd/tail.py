@@ -470,3 +470,174 @@ def linear_bn_relu_segmax(h, affine, bn, training, S, reduce_fn=None):
     W = affine.weight.view(affine.weight.shape[0], -1)
     xpre, _ = _LinearBNSegmax.apply(h, W, affine.bias, bn.weight, bn.bias, bn, training, reduce_fn, S)
     return xpre
+
+
+# ---- net3DV_3 as ONE pass structure on the row-streamed GEMMs (csrc/gemm_rs.hip) ----------------------------------------
+def rs_planes(W, transposed, centers_cols=None):
+    """Fragment-ordered bf16 planes of a weight matrix view (rows x cols, any leading dimension) for facl_gemm_rs_fwd
+    (transposed = False) / facl_gemm_rs_dgrad (True).  `centers_cols`: (N,3) view whose columns join as the centre k-step."""
+    lib = _lib.load_library()
+    N, K = W.shape
+    nb = lib.facl_gemm_rs_planes_bytes(K if transposed else N, N if transposed else K, 0 if centers_cols is None else 1)
+    planes = _lib.empty(nb, dtype=torch.uint8, device=W.device)
+    _lib.check(lib.facl_gemm_rs_planes(W.data_ptr(), W.stride(0), N, K, 1 if transposed else 0,
+                                       None if centers_cols is None else centers_cols.data_ptr(),
+                                       0 if centers_cols is None else centers_cols.stride(0), _lib.ptr(planes), _lib.stream()),
+               "facl_gemm_rs_planes")
+    return planes
+
+
+def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws):
+    lib = _lib.load_library()
+    M, K = a.shape
+    y = _lib.empty((M, N), dtype=torch.float32, device=a.device)
+    sums = _lib.empty((N, 2), dtype=torch.float64, device=a.device) if want_stats else None
+    ymax = arg = None
+    if seg_sgn is not None:
+        ymax = _lib.empty((M // 64, N), dtype=torch.float32, device=a.device)
+        arg = _lib.empty((M // 64, N), dtype=torch.int32, device=a.device)
+    ps, pt = (pro[2], pro[3]) if pro is not None else (None, None)
+    with _lib.timed("facl_gemm_rs_fwd %dx%dx%d" % (M, K, N)):
+        _lib.check(lib.facl_gemm_rs_fwd(_lib.ptr(a), M, K, _lib.ptr(planes), N, _lib.ptr(bias), _lib.ptr(ps), _lib.ptr(pt),
+                                        _lib.ptr(centers), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(seg_sgn), _lib.ptr(ymax),
+                                        _lib.ptr(arg), _lib.ptr(ws), _lib.stream()), "facl_gemm_rs_fwd")
+    return y, sums, ymax, arg
+
+
+def _rs_dgrad(dy, W, prec):
+    """da = dy W on the row-streamed kernel (fp32-grade arithmetic) or, for the opt-in backward precision, the staged one."""
+    if prec != "f32":
+        return gemm_dgrad(dy, W, prec=prec)
+    lib = _lib.load_library()
+    M, N = dy.shape
+    K = W.shape[1]
+    planes = rs_planes(W, True)
+    da = _lib.empty((M, K), dtype=torch.float32, device=dy.device)
+    with _lib.timed("facl_gemm_rs_dgrad %dx%dx%d" % (M, N, K)):
+        _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()),
+                   "facl_gemm_rs_dgrad")
+    return da
+
+
+def _wgrad_pro(dy, y, bnc, prec):
+    """dW = dy^T relu(bn(y)) with the activation recomputed while staged; falls back to a materialised activation."""
+    lib = _lib.load_library()
+    M, N = dy.shape
+    K = y.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    nz = max(1, min((M + 255) // 256, 512 // tiles))
+    dW = _lib.empty((N, K), dtype=torch.float32, device=dy.device)
+    slices = _lib.empty(nz * N * K, dtype=torch.float32, device=dy.device)
+    fn = lib.facl_gemm_wgrad_pro_x3 if prec == "x3" else lib.facl_gemm_wgrad_pro
+    with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
+        rc = fn(_lib.ptr(dy), _lib.ptr(y), M, N, K, y.stride(0), _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(dW),
+                _lib.ptr(slices), nz, _lib.stream())
+    if rc == -4:                                                        # FACL_E_CONFIG: shape not served -> materialise a
+        a = _lib.empty_like(y)
+        _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y), M, K, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a), _lib.stream()),
+                   "facl_rows_bn_relu")
+        return gemm_wgrad(dy, a, prec=prec)
+    _lib.check(rc, "facl_gemm_wgrad_pro")
+    return dW
+
+
+def net3dv3_supported(P, widths, S, prec):
+    """True when the three per-centroid layers (cn3d_model_conbag.py:61-77) run on the row-streamed kernels."""
+    import os
+    if os.environ.get("FACL_TAIL_RS", "1") == "0" or prec not in ("f32", "x3b") or S != 64 or P % 64:
+        return False
+    lib = _lib.load_library()
+    c0, c1, c2, c3 = widths
+    return all(lib.facl_gemm_rs_supported(P, k, n) == 1 for k, n in ((c0, c1), (c1, c2), (c2, c3))) and max(c1, c2) <= 512 \
+        and all(lib.facl_gemm_rs_supported(P, n, k) == 1 for k, n in ((c0, c1), (c1, c2), (c2, c3)))
+
+
+class _Net3DV3(torch.autograd.Function):
+    """x_pre = my_max_pool(net3DV_3(cat(centres, pooled)))  (cn3d_model_conbag.py:61-77, :219-223) as explicit passes:
+    three row-streamed forward GEMMs whose prologue applies the previous layer's BatchNorm + ReLU (the activations a1,
+    a2 are never written; `k_rows_bn_relu` is gone), the centre columns as one more k-step, statistics and the max over each
+    cloud's 64 centroids in the epilogues; backward = BN-backward row passes + row-streamed dgrads + weight gradients whose
+    activation operand is recomputed from the raw layer output while it is staged."""
+
+    @staticmethod
+    def forward(ctx, pooled, centers, S, training, reduce_fn, bns, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3):
+        ctx.prec = current_precision()
+        lib = _lib.load_library()
+        _lib.require_cuda(pooled)
+        ws = _Workspace.get(pooled.device)
+        pooled, centers = pooled.contiguous(), centers.contiguous()
+        W1, W2, W3 = W1.contiguous(), W2.contiguous(), W3.contiguous()
+        P = pooled.shape[0]
+        y1, sums1, _, _ = _rs_fwd(pooled, rs_planes(W1[:, 3:], False, W1[:, :3]), W1.shape[0], b1, None, centers, training,
+                                  None, ws)
+        bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1)
+        y2, sums2, _, _ = _rs_fwd(y1, rs_planes(W2, False), W2.shape[0], b2, bnc1, None, training, None, ws)
+        bnc2, _ = _forward_bn_consts(y2, bns[1], training, reduce_fn, ws, sums2)
+        y3, sums3, ymax, arg = _rs_fwd(y2, rs_planes(W3, False), W3.shape[0], b3, bnc2, None, training, g3.detach(), ws)
+        bnc3, _ = _forward_bn_consts(y3, bns[2], training, reduce_fn, ws, sums3)
+        M, C = P // S, W3.shape[0]
+        xpre = _lib.empty((M, C), dtype=torch.float32, device=pooled.device)
+        _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(xpre), _lib.stream()),
+                   "facl_sa_pool")
+        ctx.save_for_backward(pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg)
+        ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
+        return xpre
+
+    @staticmethod
+    def backward(ctx, dxpre):
+        if not ctx.training:
+            raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
+        bp = backward_precision(ctx.prec)
+        lib = _lib.load_library()
+        pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg = ctx.saved_tensors
+        ws = _Workspace.get(y1.device)
+        st = _lib.stream()
+        P, S = y1.shape[0], ctx.S
+        M = P // S
+        f64 = dict(dtype=torch.float64, device=y1.device)
+        # ---- layer 3: max-pool + BN backward on the raw output y3
+        C3 = y3.shape[1]
+        dxpre = dxpre.contiguous()
+        sums = _lib.empty((C3, 2), **f64)
+        _lib.check(lib.facl_segmax_bwd_stats(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
+                                             _lib.ptr(bnc3), _lib.ptr(sums), _lib.ptr(ws), st), "facl_segmax_bwd_stats")
+        dbe3, dga3, kk = _bn_bwd_consts(sums, C3, ctx.count, ctx.reduce_fn)
+        dy = _lib.empty_like(y3)
+        _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
+                                             _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), st), "facl_segmax_bwd_apply")
+        dW3 = _wgrad_pro(dy, y2, bnc2, bp)
+        da = _rs_dgrad(dy, W3, bp)
+        # ---- layers 2 and 1: BN backward rows passes, weight gradient with the recomputed activation, dgrad
+        grads = []
+        for y, bnc, yin, bnc_in, W in ((y2, bnc2, y1, bnc1, W2), (y1, bnc1, None, None, W1)):
+            C = y.shape[1]
+            sums = _lib.empty((C, 2), **f64)
+            _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), st),
+                       "facl_rows_bwd_stats")
+            dbe, dga, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)
+            dy = _lib.empty_like(y)
+            _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), st),
+                       "facl_rows_bwd_apply")
+            if yin is not None:
+                dW = _wgrad_pro(dy, yin, bnc_in, bp)
+                da = _rs_dgrad(dy, W, bp)
+            else:                                                       # first layer: input = pooled | centres
+                dWh = gemm_wgrad(dy, pooled, prec=bp)
+                dWc = _lib.empty((C, 3), **f64)
+                _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(centers), P, C, _lib.ptr(dWc), _lib.ptr(ws), st),
+                           "facl_rows_center_wgrad")
+                dW = torch.cat((dWc.float(), dWh), dim=1)
+                da = _rs_dgrad(dy, W[:, 3:], bp) if ctx.needs_input_grad[0] else None
+            grads.append((dW, dga, dbe))
+        (dW2, dga2, dbe2), (dW1, dga1, dbe1) = grads
+        # d(bias) of a conv in front of a train-mode BN is identically zero: None leaves the parameter untouched
+        return (da, None, None, None, None, None, dW1, None, dga1, dbe1, dW2, None, dga2, dbe2, dW3, None, dga3, dbe3)
+
+
+def net3dv3(pooled, centers, net, training, S, reduce_fn=None):
+    """`net` = the nn.Sequential-like net3DV_3 container (indices 0,1 / 3,4 / 6,7 = affine, BatchNorm of the three layers)."""
+    view = lambda a: a.weight.view(a.weight.shape[0], -1)
+    return _Net3DV3.apply(pooled, centers, S, training, reduce_fn, (net[1], net[4], net[7]),
+                          view(net[0]), net[0].bias, net[1].weight, net[1].bias,
+                          view(net[3]), net[3].bias, net[4].weight, net[4].bias,
+                          view(net[6]), net[6].bias, net[7].weight, net[7].bias)

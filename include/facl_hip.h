@@ -230,6 +230,35 @@ int facl_gemm_dgrad_f16(const float* dy, int64_t M, int N, const float* W, int l
                         void* stream);
 int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                         float* slices, int nz, void* stream);
+/* ---- row-streamed forward / dgrad for the 49,152-row layers (csrc/gemm_rs.hip) -------------------------------------------
+ * Replaces the same torch chain as facl_gemm_fwd / facl_gemm_dgrad (Conv2d 1x1 of net3DV_3, cn3d_model_conbag.py:61-77,
+ * and its autograd) with the weight operand pre-split ONCE per step into fragment-ordered bf16 planes
+ * (facl_gemm_rs_planes; caller-allocated buffer of facl_gemm_rs_planes_bytes) and the activation rows streamed through
+ * per-wave LDS slots.  Same arithmetic as facl_gemm_fwd (six bf16 products per multiply-add): bit-identical results.
+ *   facl_gemm_rs_supported   1 when (rows M, contraction K, output columns N) is served: M >= 2048, 64 <= K <= 1024,
+ *                            K % 32 == 0, N % 256 == 0; else 0 (callers then use facl_gemm_fwd / facl_gemm_dgrad)
+ *   facl_gemm_rs_planes      transposed = 0: planes for y = a W^T (W (N,K), leading dimension ldw; Wc (N,3) optional:
+ *                            the centroid-xyz columns of torch.cat((yt, xt), 1), :219); transposed = 1: planes for da = dy W
+ *   facl_gemm_rs_fwd         y = f(a) W^T + bias [+ centers Wc^T], f = relu(pscale*a + pshift) when pscale is given (the
+ *                            previous layer's BatchNorm2d + ReLU, :62-63: the activation is never materialised); sums (N,2)
+ *                            as facl_gemm_fwd; sgn / ymax / arg (all or none) as facl_gemm_fwd_segmax (M % 64 == 0)
+ *   facl_gemm_rs_dgrad       da (M,K) = dy (M,N) W
+ *   facl_gemm_wgrad_pro      dW (N,K) = dy^T relu(pscale*y + pshift): facl_gemm_wgrad whose `a` operand is recomputed from
+ *                            the previous layer's raw output y (M,K) while it is staged (the companion of the forward
+ *                            prologue: the activation tensor never exists); `_x3`: the opt-in three-product arithmetic.
+ *                            FACL_E_CONFIG when the shape is not served by the 128x128-tile kernel (callers materialise a). */
+int facl_gemm_wgrad_pro(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
+                        const float* pshift, float* dW, float* slices, int nz, void* stream);
+int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
+                           const float* pshift, float* dW, float* slices, int nz, void* stream);
+int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
+int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, void* planes,
+                        void* stream);
+int facl_gemm_rs_supported(int64_t M, int K, int N);
+int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int N, const float* bias, const float* pscale,
+                     const float* pshift, const float* centers, float* y, double* sums, const float* sgn, float* ymax,
+                     int32_t* arg, void* ws, void* stream);
+int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int K, float* da, void* stream);
 /* "bf16x3" twins (opt-in precision "x3"; never the default): each operand keeps its two leading bf16 pieces and a
  * multiply-add is three products (hi*mid, mid*hi, hi*hi) instead of six -- relative error of a product <= 3 * 2^-16
  * (results ~1e-5 of an fp64 GEMM; the north_star's tolerance for features / loss is 1e-4), half the MFMA work. */

@@ -1,0 +1,9 @@
+#!/bin/bash
+for i in 1 2 3; do
+  for v in new old; do
+    unset FACL_LIB
+    [ $v = old ] && export FACL_LIB=$PWD/scratch/lib_old.so
+    timeout -k 10 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys;d=json.loads(sys.stdin.read());r=[d['roofline']]+d['roofline_more'];f={x['kernel']:x['ms_per_launch'] for x in r if 'gemm' in x['kernel'] and '49152' in x['kernel']};print('$v',d['ms_per_step'],d['final_loss'],' '.join(f'{v:.4f}' for k,v in sorted(f.items())))"
+  done
+done

@@ -1,0 +1,673 @@
+// fp32 MFMA GEMM for the dense 1x1 "point-MLP" channel contractions of the encoder tail
+// (net3DV_3 / netR_FC: cn3d_model_conbag.py:61-88), forward, dgrad and wgrad, with the BatchNorm plumbing
+// fused in:  * prologue  A' = relu(pscale[k]*A + pshift[k])  applied while the A tile is staged (forward),
+//            * epilogue  + bias[n], + rank-3 centre term (the xyz columns of torch.cat((yt, xt),1), :219),
+//                        per-column (sum, sumsq) partials for the train-mode BN that follows,
+//            * split-K partial tiles for the weight gradient (contraction over the 49,152 centroid rows).
+//
+//   C[i][j] = sum_k  opA(i,k) * opB(j,k)        i < MI, j < NJ, k < KK
+// Operand layouts (element (idx,k)):  KC ("k-contiguous")  ptr[idx*ld + k]   rows of activations / weights
+//                                     IC ("idx-contiguous") ptr[k*ld + idx]   the transposed views of dgrad/wgrad
+//   forward  y  = a W^T      : A = a  (KC), B = W (KC)
+//   dgrad    da = dy W       : A = dy (KC), B = W (IC)          (k = output channel)
+//   wgrad    dW = dy^T a     : A = dy (IC), B = a (IC)          (k = row, split over blockIdx.z)
+// Tile 128x128x32, 256 threads = 2x2 waves of 64x64 (2x2 v_mfma_f32_32x32x2_f32 tiles, 64 accumulators),
+// operands staged global -> registers -> LDS as [k][idx] (+4 pad) so that the MFMA fragments are
+// conflict-free ds_read_b32; register prefetch of the next k-tile overlaps the 64 MFMAs of the current one.
+// Roofline: MFMA fp32 (157.3 TFLOP/s); 2*MI*NJ*KK FLOP per call.
+#include "common.h"
+#include <stdlib.h>
+
+int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;      // KC tiles: LDS image [idx][k], row = 36 floats: b128 writes AND b128 fragment reads
+                                 // are conflict-free (36*q mod 64 hits 16 distinct 4-dword slots for 16 lanes)
+// IC tiles: LDS image [k][idx], row = NIDX+4 floats (16-B aligned rows).  NIDX = 64*T (T = 32x32 tiles per wave side)
+enum { KC = 0, IC = 1 };
+
+struct GemmArgs {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int MI, NJ, KK;
+    const float* bias;                 // (NJ) or null
+    const float* pscale; const float* pshift;   // (KK) prologue on A, or null
+    const float* xa; const float* xb; int ldxb;  // rank-3 extra term: C += xa[i][0..2] . xb[j][0..2]  (or null)
+    double* part;                      // column statistics partials [(MI/64)][NJ][2], or null
+    int kchunk;                        // split-K: k range per blockIdx.z (wgrad); C then is [z][MI][NJ]
+};
+
+template <int LAY, int T>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                          float4 (&r)[2 * T], int tid) {
+    // (64T) idx x 32 k = 512T float4; thread t takes 2T of them
+    if (LAY == IC) {      // float4 along idx: 16T float4 per k-row
+#pragma unroll
+        for (int i = 0; i < 2 * T; ++i) {
+            const int k = k0 + tid / (16 * T) + (16 / T) * i, idx = idx0 + 4 * (tid % (16 * T));
+            if (k < kend && idx + 3 < nidx) r[i] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + idx);
+            else {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (k < kend && idx + e < nidx) ? P[(size_t)k * ld + idx + e] : 0.f;
+                r[i] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    } else {              // float4 along k: 8 lanes cover one 128-B row segment (full cache lines per wave-instruction;
+                          // one-row-per-lane "fragment-shaped" loads touch 64 lines per instruction instead of 8)
+#pragma unroll
+        for (int i = 0; i < 2 * T; ++i) {
+            const int idx = idx0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+            if (idx < nidx && k + 3 < kend) r[i] = *reinterpret_cast<const float4*>(P + (size_t)idx * ld + k);
+            else {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (idx < nidx && k + e < kend) ? P[(size_t)idx * ld + k + e] : 0.f;
+                r[i] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    }
+}
+
+template <int LAY, bool PRO, int TT>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&r)[2 * TT], int tid, int k0,
+                                           const float* __restrict__ ps, const float* __restrict__ pt) {
+    constexpr int LDT = 64 * TT + 4;
+    if (LAY == IC) {
+#pragma unroll
+        for (int i = 0; i < 2 * TT; ++i) {
+            const int k = tid / (16 * TT) + (16 / TT) * i;
+            *reinterpret_cast<float4*>(&T[k * LDT + 4 * (tid % (16 * TT))]) = r[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * TT; ++i) {
+            const int k = 4 * (tid & 7), il = (tid >> 3) + 32 * i;
+            float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+            if (PRO) {
+                const float4 s = *reinterpret_cast<const float4*>(ps + k0 + k);
+                const float4 t = *reinterpret_cast<const float4*>(pt + k0 + k);
+                v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
+                v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
+            }
+            *reinterpret_cast<float4*>(&T[il * LDK + k]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// XCD-aware tile order: workgroup b of the linearised grid is dispatched to XCD b % 8 (8 XCDs, one L2 each).  Remap so
+// that each XCD works through a CONTIGUOUS range of logical tiles: the column tiles that share an A row-panel (and
+// all tiles of one split-K slice) then hit the same L2 instead of pulling the panel through the fabric 8 times.
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile() {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int total = nbx * nby * gridDim.z;
+    const int b = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+    const int per = total >> 3, rem = total & 7, xcd = b & 7, slot = b >> 3;
+    const int L = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    TileId t;
+    t.x = L % nbx; t.y = (L / nbx) % nby; t.z = L / (nbx * nby);
+    return t;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int i0, int j0,
+                                              int wave, int lane, int by, int bz) {
+    const int h = lane >> 5, q = lane & 31, wr = wave >> 1, wc = wave & 1;
+    // ---- epilogue.  The accumulators hold (lane = column, register = row): column statistics are in-lane sums;
+    // the tile itself is transposed through LDS (the staging buffers are free now) so that it leaves as
+    // 16-byte-per-lane row-major stores (4-byte stores are store-ISSUE bound).
+    constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
+    float* Cz = g.C + (size_t)bz * g.MI * g.ldc;
+    float* stg = smem + wave * (WR * SP);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + WC * wc + 32 * b + q;
+        const bool jin = j < g.NJ;
+        const float bias = (g.bias && jin) ? g.bias[j] : 0.f;
+        float xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
+        if (g.xa && jin) { xb0 = g.xb[(size_t)j * g.ldxb]; xb1 = g.xb[(size_t)j * g.ldxb + 1]; xb2 = g.xb[(size_t)j * g.ldxb + 2]; }
+        float s = 0.f, sq = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = 32 * a + rowmap(r, h);
+                const int i = i0 + WR * wr + il;
+                float v = acc[a][b][r] + bias;
+                if (g.xa && i < g.MI)
+                    v = fmaf(g.xa[(size_t)i * 3], xb0, fmaf(g.xa[(size_t)i * 3 + 1], xb1, fmaf(g.xa[(size_t)i * 3 + 2], xb2, v)));
+                stg[il * SP + 32 * b + q] = v;
+                if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
+            }
+        if (g.part) {
+            const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+            if (h == 0 && jin) {
+                double* pr = g.part + ((size_t)(by * 2 + wr) * g.NJ + j) * 2;
+                pr[0] = (double)st; pr[1] = (double)sqt;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // same-wave LDS hand-off (lanes swap roles)
+    const int jw = j0 + WC * wc;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + WC <= g.NJ);
+    constexpr int LPR = WC / 4;                                            // lanes per row (float4 each)
+#pragma unroll
+    for (int t = 0; t < WR * LPR / 64; ++t) {
+        const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
+        const int i = i0 + WR * wr + il;
+        if (i >= g.MI) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
+        if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
+        else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
+        }
+    }
+}
+
+template <int LA, int LB, bool PRO, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;
+    constexpr int AF = (LA == KC) ? BM * LDK : BK * LDA, BF = (LB == KC) ? BN * LDK : BK * LDB;
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);                 // epilogue staging: 4 waves x rows x padded cols
+    constexpr int SMEM = (2 * (AF + BF) > STG) ? 2 * (AF + BF) : STG;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const sA0 = smem;                     // stage s of A at sA0 + s*AF, of B at sB0 + s*BF
+    float* const sB0 = smem + 2 * AF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * BM, j0 = tile.x * BN;
+    const int kbeg = tile.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[2 * TM], rb[2 * TN];
+    load_tile<LA, TM>(g.A, g.lda, i0, g.MI, kbeg, kend, ra, tid);
+    load_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, kbeg, kend, rb, tid);
+    store_tile<LA, PRO, TM>(sA0, ra, tid, kbeg, g.pscale, g.pshift);
+    store_tile<LB, false, TN>(sB0, rb, tid, kbeg, nullptr, nullptr);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {
+            load_tile<LA, TM>(g.A, g.lda, i0, g.MI, k0 + BK, kend, ra, tid);
+            load_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, k0 + BK, kend, rb, tid);
+        }
+        // MFMA k-slot of half h in step s is k = 16h + s for BOTH operands (any bijection works)
+        const float* pa = sA0 + cur * AF;
+        const float* pb = sB0 + cur * BF;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float av[TM][4], bv[TN][4];
+            // KC operands: one b128 read fetches this lane's 4 consecutive k of the step group;
+            // IC operands are read one k at a time right before their MFMAs (finer LDS / MFMA interleave)
+            if (LA == KC) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const float4 u = *reinterpret_cast<const float4*>(&pa[(32 * TM * wr + 32 * a + q) * LDK + 16 * h + 4 * s4]);
+                    av[a][0] = u.x; av[a][1] = u.y; av[a][2] = u.z; av[a][3] = u.w;
+                }
+            }
+            if (LB == KC) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const float4 u = *reinterpret_cast<const float4*>(&pb[(32 * TN * wc + 32 * b + q) * LDK + 16 * h + 4 * s4]);
+                    bv[b][0] = u.x; bv[b][1] = u.y; bv[b][2] = u.z; bv[b][3] = u.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (LA == IC) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) av[a][e] = pa[(16 * h + 4 * s4 + e) * LDA + 32 * TM * wr + 32 * a + q];
+                }
+                if (LB == IC) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bv[b][e] = pb[(16 * h + 4 * s4 + e) * LDB + 32 * TN * wc + 32 * b + q];
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(av[a][e], bv[b][e], acc[a][b]);
+            }
+        }
+        if (more) {
+            store_tile<LA, PRO, TM>(sA0 + (cur ^ 1) * AF, ra, tid, k0 + BK, g.pscale, g.pshift);
+            store_tile<LB, false, TN>(sB0 + (cur ^ 1) * BF, rb, tid, k0 + BK, nullptr, nullptr);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write
+// instructions, no vmcnt wait in front of an LDS store).  The DMA destination is lane-linear (wave-uniform base +
+// lane*16 B), so the LDS images are UNPADDED and the bank-conflict swizzle lives on the SOURCE address:
+//   KC tile [idx][32 floats]: 8 lanes per 128-B row; the 16-B piece that lands in physical quad c' of row r is
+//        logical quad c' ^ ((r>>1)&7); the b128 fragment read of logical quad c uses physical c ^ ((r>>1)&7)
+//        (conflict-free for the ds_read_b128 lane groups of gfx950: checked by enumeration in DESIGN.md);
+//   IC tile [k][64T floats]: rows are already read along idx with b32 -> no swizzle.
+// Out-of-range rows / k read a 16-byte zero word instead (the source address is per lane).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int LAY, int T>
+__device__ __forceinline__ void dma_tile(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                         float* lds_tile, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (LAY == KC) {                 // pass i: rows 32i + 8w + (lane>>3), physical quad lane&7
+#pragma unroll
+        for (int i = 0; i < 2 * T; ++i) {
+            const int r = 32 * i + 8 * wave + (lane >> 3);
+            const int cq = (lane & 7) ^ ((r >> 1) & 7);
+            const int idx = idx0 + r, k = k0 + 4 * cq;
+            const float* src = (idx < nidx && k < kend) ? P + (size_t)idx * ld + k : g_zero16;
+            float* dst = lds_tile + (32 * i + 8 * wave) * 32;          // wave-uniform; lane*16 B is implicit
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    } else {                         // [k][64T]: one wave-instruction = 256 floats = 4/T k-rows... (64T floats per row)
+        constexpr int RPI = 256 / (64 * T);          // k-rows per wave-instruction (2 for T=2, 4 for T=1)
+#pragma unroll
+        for (int i = 0; i < 2 * T; ++i) {
+            const int krow = RPI * (4 * i + wave) + lane / (16 * T);
+            const int idx = idx0 + 4 * (lane % (16 * T)), k = k0 + krow;
+            const float* src = (idx < nidx && k < kend) ? P + (size_t)k * ld + idx : g_zero16;
+            float* dst = lds_tile + RPI * (4 * i + wave) * (64 * T);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    }
+}
+
+template <int LA, int LB, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm_dma(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AF = BM * BK, BF = BN * BK;                          // unpadded images
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);
+    constexpr int SMEM = (2 * (AF + BF) > STG) ? 2 * (AF + BF) : STG;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const sA0 = smem;
+    float* const sB0 = smem + 2 * AF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * BM, j0 = tile.x * BN;
+    const int kbeg = tile.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    dma_tile<LA, TM>(g.A, g.lda, i0, g.MI, kbeg, kend, sA0, tid);
+    dma_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, kbeg, kend, sB0, tid);
+    __syncthreads();                                                   // drains the DMAs (vmcnt(0)) + barrier
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (k0 + BK < kend) {
+            dma_tile<LA, TM>(g.A, g.lda, i0, g.MI, k0 + BK, kend, sA0 + (cur ^ 1) * AF, tid);
+            dma_tile<LB, TN>(g.B, g.ldb, j0, g.NJ, k0 + BK, kend, sB0 + (cur ^ 1) * BF, tid);
+        }
+        const float* pa = sA0 + cur * AF;
+        const float* pb = sB0 + cur * BF;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float av[TM][4], bv[TN][4];
+            if (LA == KC) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int r = 32 * TM * wr + 32 * a + q;
+                    const float4 u = *reinterpret_cast<const float4*>(&pa[r * 32 + 4 * ((4 * h + s4) ^ ((r >> 1) & 7))]);
+                    av[a][0] = u.x; av[a][1] = u.y; av[a][2] = u.z; av[a][3] = u.w;
+                }
+            }
+            if (LB == KC) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int r = 32 * TN * wc + 32 * b + q;
+                    const float4 u = *reinterpret_cast<const float4*>(&pb[r * 32 + 4 * ((4 * h + s4) ^ ((r >> 1) & 7))]);
+                    bv[b][0] = u.x; bv[b][1] = u.y; bv[b][2] = u.z; bv[b][3] = u.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (LA == IC) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) av[a][e] = pa[(16 * h + 4 * s4 + e) * BM + 32 * TM * wr + 32 * a + q];
+                }
+                if (LB == IC) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bv[b][e] = pb[(16 * h + 4 * s4 + e) * BN + 32 * TN * wc + 32 * b + q];
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(av[a][e], bv[b][e], acc[a][b]);
+            }
+        }
+        __syncthreads();                                               // next tile landed, this one free
+        cur ^= 1;
+    }
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-bf16 variant ("bf16x6"): the fp32 MFMA of gfx950 runs at 1/16 of the bf16 MFMA rate, so each fp32 operand
+// is split EXACTLY into three bf16 pieces while its tile is staged (x = hi + mid + lo, round-to-nearest at each
+// level: 3 x 8 mantissa bits + the sign trick cover the 24-bit significand) and the product is accumulated from the
+// six piece products whose magnitude reaches 2^-24 of |a||b|:
+//      a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh)   [+ am*bl + al*bm + al*bl  <= 2^-25 |a||b|, dropped]
+// Every bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result has
+// fp32-GEMM accuracy (tests/test_gpu_gemm.py compares both paths with an fp64 product) at 6/16 of the MFMA time.
+// LDS image per operand: [piece][idx][32 k + 8 pad] bf16 (80-B rows: the ds_read_b128 fragment reads and the
+// staging writes are conflict-free); both global layouts are transposed into it by the register staging pass.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr int SBROW = BK + 8;                  // bf16 elements per LDS row
+
+__device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
+    const f32x2v v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));       // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mi, unsigned& lo) {
+    hi = pk_bf16(x0, x1); mi = hi; lo = hi; return;
+    // scalar subtractions on purpose: the SLP vectoriser would fuse each pair into v_pk_add_f32, which costs far more
+    // than two v_sub_f32 beside MFMAs (MI355X guide, "packed f32 VALU ... an anti-lever beside MFMAs")
+    const float r0 = sub_f32(x0, __builtin_bit_cast(float, hi << 16)), r1 = sub_f32(x1, __builtin_bit_cast(float, hi & 0xffff0000u));
+    mi = pk_bf16(r0, r1);
+    const float s0 = sub_f32(r0, __builtin_bit_cast(float, mi << 16)), s1 = sub_f32(r1, __builtin_bit_cast(float, mi & 0xffff0000u));
+    lo = pk_bf16(s0, s1);
+}
+
+// Branch-free tile fetches for the split path (a tile whose loads sit in 2T if/else blocks defeats the scheduler):
+// addresses are CLAMPED into the operand (rows beyond nidx re-read the last row: they only feed output rows / columns
+// that the epilogue never stores or counts), and k beyond kend -- possible only in the last, partial stage of a
+// contraction that is not a multiple of 32 -- is zeroed by select (FULL = false instantiation).
+template <int T, bool FULL>
+__device__ __forceinline__ void load_tile_kc4(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                              float4 (&r)[2 * T], int tid) {
+    const int k = k0 + 4 * (tid & 7);
+    const int kc = FULL ? k : (k + 3 < kend ? k : kend - 4);        // KK % 4 == 0 and KK >= 4 (checked by the callers)
+#pragma unroll
+    for (int i = 0; i < 2 * T; ++i) {
+        int idx = idx0 + (tid >> 3) + 32 * i;
+        idx = idx < nidx ? idx : nidx - 1;
+        float4 v = *reinterpret_cast<const float4*>(P + (size_t)idx * ld + kc);
+        if (!FULL && k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        r[i] = v;
+    }
+}
+
+// IC operands for the split path: thread t owns idx = t % (64T) and T chunks of 8 consecutive k (dword loads,
+// coalesced along idx), so that the 8 k of a chunk leave as ONE 16-byte LDS row piece per bf16 plane.
+template <int T, bool FULL>
+__device__ __forceinline__ void load_tile_ic8(const float* __restrict__ P, int ld, int idx0, int nidx, int k0, int kend,
+                                              float (&r)[8 * T], int tid) {
+    int idx = idx0 + tid % (64 * T);
+    idx = idx < nidx ? idx : nidx - 1;
+    const int kc = tid / (64 * T);
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 8 * (kc + (4 / T) * i) + j;
+            const int kk = FULL ? k : (k < kend ? k : kend - 1);
+            const float v = P[(size_t)kk * ld + idx];
+            r[8 * i + j] = (FULL || k < kend) ? v : 0.f;
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void store_tile_ic8(unsigned short* __restrict__ S, const float (&r)[8 * T], int tid) {
+    constexpr int PLANE = 64 * T * SBROW;
+    const int il = tid % (64 * T), kc = tid / (64 * T);
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], hi[j], mi[j], lo[j]);
+        unsigned short* d = S + il * SBROW + 8 * (kc + (4 / T) * i);
+        *reinterpret_cast<uint4*>(d) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(d + PLANE) = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        *reinterpret_cast<uint4*>(d + 2 * PLANE) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+template <bool PRO, int T>
+__device__ __forceinline__ void store_tile_kc4(unsigned short* __restrict__ S, const float4 (&r)[2 * T], int tid, int k0,
+                                               const float* __restrict__ ps, const float* __restrict__ pt) {
+    constexpr int PLANE = 64 * T * SBROW;
+#pragma unroll
+    for (int i = 0; i < 2 * T; ++i) {
+        const int k = 4 * (tid & 7), il = (tid >> 3) + 32 * i;
+        float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        if (PRO) {
+            const float4 s = *reinterpret_cast<const float4*>(ps + k0 + k);
+            const float4 t = *reinterpret_cast<const float4*>(pt + k0 + k);
+            v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
+            v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
+        }
+        unsigned hi[2], mi[2], lo[2];
+        split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
+        split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
+        unsigned short* d = S + il * SBROW + k;
+        *reinterpret_cast<uint2*>(d) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(mi[0], mi[1]);
+        *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(lo[0], lo[1]);
+    }
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int LA, int LB, bool PRO, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int APL = BM * SBROW, BPL = BN * SBROW;                   // one bf16 plane of each operand (elements)
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);                  // epilogue staging (floats)
+    constexpr int TILE_F = (3 * (APL + BPL) * 2 + 3) / 4;               // operand images in floats
+    constexpr int SMEM = TILE_F > STG ? TILE_F : STG;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    unsigned short* const sA = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const sB = sA + 3 * APL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const TileId tile = xcd_tile();
+    const int i0 = tile.y * BM, j0 = tile.x * BN;
+    const int kbeg = tile.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra4[2 * TM], rb4[2 * TN];
+    float ra8[8 * TM], rb8[8 * TN];
+    auto fetch = [&](int k0) {
+        if (k0 + BK <= kend) {                                         // wave-uniform
+            if (LA == KC) load_tile_kc4<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
+            else load_tile_ic8<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
+            if (LB == KC) load_tile_kc4<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
+            else load_tile_ic8<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
+        } else {
+            if (LA == KC) load_tile_kc4<TM, false>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
+            else load_tile_ic8<TM, false>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
+            if (LB == KC) load_tile_kc4<TN, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
+            else load_tile_ic8<TN, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
+        }
+    };
+    auto stage = [&](int k0) {
+        if (LA == KC) store_tile_kc4<PRO, TM>(sA, ra4, tid, k0, g.pscale, g.pshift);
+        else store_tile_ic8<TM>(sA, ra8, tid);
+        if (LB == KC) store_tile_kc4<false, TN>(sB, rb4, tid, k0, nullptr, nullptr);
+        else store_tile_ic8<TN>(sB, rb8, tid);
+    };
+    fetch(kbeg);
+    stage(kbeg);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more && g.KK == 12345) fetch(k0 + BK);
+        __builtin_amdgcn_sched_barrier(0);                             // all loads in flight before the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk) __builtin_amdgcn_sched_barrier(0);
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * APL + (32 * TM * wr + 32 * a + q) * SBROW + 16 * kk + 8 * h);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[b][p] = *reinterpret_cast<const bf16x8*>(sB + p * BPL + (32 * TN * wc + 32 * b + q) * SBROW + 16 * kk + 8 * h);
+            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][PA[t]], bf[b][PB[t]], acc[a][b]);
+        }
+        __syncthreads();                                               // every wave has read this stage
+        if (more && g.KK == 12345) stage(k0 + BK);
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
+}
+
+// sum over split-K slices: out[e] = sum_z part[z][e]
+__global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n4, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 s = reinterpret_cast<const float4*>(part)[i];
+        for (int z = 1; z < nz; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+// tile choice: 128x128 blocks when they already fill the chip, else 64x64 blocks (4x the workgroups) -- the FC head
+// (M = 768 or 32 rows) would otherwise run on 48 or 8 of the 256 CUs
+template <int LA, int LB, bool PRO>
+int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
+    const long long big = (long long)((g.NJ + 127) / 128) * ((g.MI + 127) / 128) * nz;
+    static const int use_dma = getenv("FACL_GEMM_DMA") ? atoi(getenv("FACL_GEMM_DMA")) : 1;
+    // FACL_GEMM_F32=1 selects the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split-bf16 ones
+    static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
+    if (!use_f32) {
+        if (big >= 256) {
+            dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 64;
+        } else {
+            dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 32;
+        }
+        return facl_launch_status();
+    }
+    // LDS-DMA needs 16-byte aligned 4-element pieces: leading dimensions and extents multiples of 4
+    // Measured A/B in one process (49152-row layers): the DMA path wins when BOTH operands are idx-contiguous
+    // (wgrad: 0.431 vs 0.538 ms at 1024x512) and loses a few % when a k-contiguous operand needs the
+    // source-side swizzle (forward 0.564 vs 0.552, dgrad 0.475 vs 0.460) -> used for wgrad only.
+    const bool dma_ok = use_dma && !PRO && LA == IC && LB == IC && !(g.lda & 3) && !(g.ldb & 3) && !(g.MI & 3) &&
+                        !(g.NJ & 3) && !(((uintptr_t)g.A | (uintptr_t)g.B) & 15);
+    if (big >= 256) {
+        dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+        if (dma_ok) hipLaunchKernelGGL((k_gemm_dma<LA, LB, 2, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
+        if (rows_per_part) *rows_per_part = 64;
+    } else {
+        dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+        if (dma_ok) hipLaunchKernelGGL((k_gemm_dma<LA, LB, 1, 1>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
+        if (rows_per_part) *rows_per_part = 32;
+    }
+    return facl_launch_status();
+}
+
+}  // namespace
+
+// y (M,N) = opA(a) W^T + bias (+ centres term), optional BN+ReLU prologue on a, optional column statistics
+extern "C" int facl_gemm_fwd(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
+                             const float* pscale, const float* pshift, const float* centers, const float* Wc,
+                             int ldwc, float* y, double* sums, void* ws, void* stream) {
+    if (!a || !W || !y || (sums && !ws)) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || K < 4 || (K & 3) || N < 1 || (ldw & 3)) return FACL_E_SHAPE;
+    if ((pscale == nullptr) != (pshift == nullptr) || (centers == nullptr) != (Wc == nullptr)) return FACL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, pscale, pshift, centers, Wc, ldwc,
+               sums ? (double*)ws : nullptr, K};
+    int rpp = 64;
+    int rc = pscale ? launch<KC, KC, true>(g, 1, st, &rpp) : launch<KC, KC, false>(g, 1, st, &rpp);
+    if (rc || !sums) return rc;
+    const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
+    if ((size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    // rows of the last (partial) tile that no wave wrote hold stale data only if M % 64 != 0 for the last
+    // wave-row; such partial rows contribute nothing because those waves stored s = sq = 0.
+    return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
+}
+
+// da (M,K) = dy (M,N) W (N,K)        (W row-major with leading dimension ldw; pass W + offset to skip columns)
+extern "C" int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da,
+                               void* stream) {
+    if (!dy || !W || !da) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 1) return FACL_E_SHAPE;
+    GemmArgs g{dy, N, W, ldw, da, K, (int)M, K, N, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, N};
+    return launch<KC, IC, false>(g, 1, (hipStream_t)stream, nullptr);
+}
+
+// dW (N,K) = dy^T (N,M) a (M,K), split over nz row chunks; `slices` is scratch for nz*N*K floats
+extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
+                               float* slices, int nz, void* stream) {
+    if (!dy || !a || !dW || !slices) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk = (int)((M + nz - 1) / nz);
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    nz = (int)((M + kchunk - 1) / kchunk);
+    GemmArgs g{dy, N, a, lda, slices, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, kchunk};
+    int rc = launch<IC, IC, false>(g, nz, st, nullptr);
+    if (rc) return rc;
+    const long long n4 = (long long)N * K / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid), dim3(256), 0, st, slices, nz, n4, dW);
+    return facl_launch_status();
+}

@@ -15,7 +15,8 @@
 // operands staged global -> registers -> LDS as [k][idx] (+4 pad) so that the MFMA fragments are
 // conflict-free ds_read_b32; register prefetch of the next k-tile overlaps the 64 MFMAs of the current one.
 // Roofline: MFMA fp32 (157.3 TFLOP/s); 2*MI*NJ*KK FLOP per call.
-#include "common.h"
+#include "../facl_amd/csrc/common.h"
+#include <utility>
 #include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
@@ -189,95 +190,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
-        }
-    }
-}
-
-// The same epilogue staged 32 rows (one MFMA row tile) at a time: half the LDS of gemm_epilogue for 128x128 blocks (35 KiB
-// instead of 69 KiB).  Used by the fp16-input instantiation, whose operand images are small (one plane): three workgroups
-// per CU instead of two for GEMMs that are latency-bound (4-8 stages per tile at K = 128 / 256).  Per-column state
-// (statistics, running max) lives in registers across the row-tile passes; sums accumulate in the same order.
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_h(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int i0, int j0,
-                                                int wave, int lane, int by, int bz) {
-    const int h = lane >> 5, q = lane & 31, wr = wave >> 1, wc = wave & 1;
-    constexpr int WR = 32 * TM, WC = 32 * TN, SP = WC + 4;
-    float* Cz = g.C + (size_t)bz * g.MI * g.ldc;
-    float* stg = smem + wave * (32 * SP);
-    float bias[TN], xb0[TN], xb1[TN], xb2[TN], s[TN], sq[TN], sg[TN], best[TN];
-    int bp[TN];
-    bool jin[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + WC * wc + 32 * b + q;
-        jin[b] = j < g.NJ;
-        bias[b] = (g.bias && jin[b]) ? g.bias[j] : 0.f;
-        xb0[b] = xb1[b] = xb2[b] = 0.f;
-        if (g.xa && jin[b]) { xb0[b] = g.xb[(size_t)j * g.ldxb]; xb1[b] = g.xb[(size_t)j * g.ldxb + 1]; xb2[b] = g.xb[(size_t)j * g.ldxb + 2]; }
-        s[b] = sq[b] = 0.f;
-        sg[b] = (g.smax && jin[b]) ? sgn_of(g.sgn[j]) : 1.f;
-        best[b] = 0.f;
-        bp[b] = 0;
-    }
-    const int jw = j0 + WC * wc;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (jw + WC <= g.NJ);
-    constexpr int LPR = WC / 4;                                            // lanes per row (float4 each)
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = rowmap(r, h);
-                const int i = i0 + WR * wr + 32 * a + il;
-                float v = acc[a][b][r] + bias[b];
-                if (g.xa && i < g.MI)
-                    v = fmaf(g.xa[(size_t)i * 3], xb0[b], fmaf(g.xa[(size_t)i * 3 + 1], xb1[b], fmaf(g.xa[(size_t)i * 3 + 2], xb2[b], v)));
-                stg[il * SP + 32 * b + q] = v;
-                if (i < g.MI && jin[b]) { s[b] += v; sq[b] = fmaf(v, v, sq[b]); }
-                if (TM == 2 && g.smax) {
-                    const float sv = sg[b] * v;
-                    if ((a == 0 && r == 0) || sv > best[b]) { best[b] = sv; bp[b] = 32 * a + rowmap(r, 0); }
-                }
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // same-wave LDS hand-off (lanes swap roles)
-#pragma unroll
-        for (int t = 0; t < 32 * LPR / 64; ++t) {
-            const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
-            const int i = i0 + WR * wr + 32 * a + il;
-            if (i >= g.MI) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
-            if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
-            else {
-                const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
-            }
-        }
-        asm volatile("" ::: "memory");                                     // the next row tile reuses the staging rows
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + WC * wc + 32 * b + q;
-        if (TM == 2 && g.smax) {                                           // the wave tile's 64 rows = one cloud
-            int p = bp[b] + 4 * h;
-            float bv = best[b];
-            const float ob = __shfl_xor(bv, 32, 64);
-            const int op = __shfl_xor(p, 32, 64);
-            if (ob > bv || (ob == bv && op < p)) { bv = ob; p = op; }      // first max wins (MaxPool2d)
-            if (h == 0 && jin[b]) {
-                const size_t o = (size_t)((i0 + WR * wr) >> 6) * g.NJ + j;
-                g.smax[o] = bv;
-                g.sarg[o] = p;
-            }
-        }
-        if (g.part) {
-            const float st = s[b] + __shfl_xor(s[b], 32, 64), sqt = sq[b] + __shfl_xor(sq[b], 32, 64);
-            if (h == 0 && jin[b]) {
-                double* pr = g.part + ((size_t)(by * 2 + wr) * g.NJ + j) * 2;
-                pr[0] = (double)st; pr[1] = (double)sqt;
-            }
         }
     }
 }
@@ -537,26 +449,21 @@ __device__ __forceinline__ void load_tile_ic8(const float* __restrict__ P, int l
 // Staging is two-phase so that the conversion overlaps the MFMAs: split_tile_* turns the raw fp32 registers of the
 // NEXT stage into packed bf16 planes (VALU only, scheduled between the MFMAs of the current stage), write_tile_*
 // is the bare LDS store between the two workgroup barriers.  PK = 12T packed registers per operand.
-// NP = 3: exact 3-way bf16 split; NP = 2: the two leading bf16 pieces ("bf16x3", common.h); NP = 1: one fp16 plane
-// (round to nearest), for the fp16-input MFMA
+// NP = 3: exact 3-way bf16 split; NP = 1: one fp16 plane (round to nearest), for the fp16-input MFMA
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned pk_f16(float x0, float x1) {
     const f32x2v v = {x0, x1};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
 }
-// PROI: relu(ps * x + pt) with the constants of the thread's OWN idx (an idx-contiguous operand whose prologue runs over
-// idx, not over k: the `a` operand of a weight gradient, a = relu(bn(y)) recomputed from the raw layer output)
-template <int T, int NP, bool PROI = false>
-__device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned (&pk)[12 * T], float ps = 1.f, float pt = 0.f) {
+template <int T, int NP>
+__device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned (&pk)[12 * T]) {
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float x0 = r[8 * i + 2 * j], x1 = r[8 * i + 2 * j + 1];
-            if (PROI) { x0 = fmaxf(fmaf(ps, x0, pt), 0.f); x1 = fmaxf(fmaf(ps, x1, pt), 0.f); }
-            if (NP >= 2) split_pair(x0, x1, pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
-            else pk[12 * i + j] = pk_f16(x0, x1);
+            if (NP == 3) split_pair(r[8 * i + 2 * j], r[8 * i + 2 * j + 1], pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
+            else pk[12 * i + j] = pk_f16(r[8 * i + 2 * j], r[8 * i + 2 * j + 1]);
         }
 }
 template <int T, int NP>
@@ -586,7 +493,7 @@ __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigne
             v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
             v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
         }
-        if (NP >= 2) {
+        if (NP == 3) {
             split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
             split_pair(v[2], v[3], pk[6 * i + 1], pk[6 * i + 3], pk[6 * i + 5]);
         } else {
@@ -607,18 +514,16 @@ __device__ __forceinline__ void write_tile_kc4(unsigned short* __restrict__ S, c
 }
 
 
-template <int LA, int LB, bool PRO, int TM, int TN, int NP = 3>
-__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
+template <int LA, int LB, bool PRO, int TM, int TN, int NP = 3, int DEPTH = 1>
+__global__ __launch_bounds__(256, 2) void k_gemm_sb(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int APL = BM * SBROW, BPL = BN * SBROW;                   // one bf16 plane of each operand (elements)
-    // epilogue staging (floats): the fp16-input instantiation stages one 32-row tile at a time (gemm_epilogue_h) and keeps
-    // only its single operand plane -> 35 KiB of LDS, three workgroups per CU
-    constexpr int STG = NP == 1 ? 4 * 32 * (32 * TN + 4) : 4 * (32 * TM) * (32 * TN + 4);
-    constexpr int TILE_F = ((NP == 1 ? 1 : 3) * (APL + BPL) * 2 + 3) / 4;   // operand images in floats
+    constexpr int STG = 4 * (32 * TM) * (32 * TN + 4);                  // epilogue staging (floats)
+    constexpr int TILE_F = (3 * (APL + BPL) * 2 + 3) / 4;               // operand images in floats
     constexpr int SMEM = TILE_F > STG ? TILE_F : STG;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     unsigned short* const sA = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* const sB = sA + (NP == 1 ? 1 : 3) * APL;
+    unsigned short* const sB = sA + 3 * APL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const TileId tile = xcd_tile();
@@ -634,35 +539,25 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra4[2 * TM], rb4[2 * TN];
-    float ra8[8 * TM], rb8[8 * TN];
-    auto fetch = [&](int k0) {
-        if (k0 + BK <= kend) {                                         // wave-uniform
-            if (LA == KC) load_tile_kc4<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
-            else load_tile_ic8<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
-            if (LB == KC) load_tile_kc4<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
-            else load_tile_ic8<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
-        } else {
-            if (LA == KC) load_tile_kc4<TM, false>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
-            else load_tile_ic8<TM, false>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
-            if (LB == KC) load_tile_kc4<TN, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
-            else load_tile_ic8<TN, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
-        }
+    float4 ra4[DEPTH][2 * TM], rb4[DEPTH][2 * TN];
+    float ra8[DEPTH][8 * TM], rb8[DEPTH][8 * TN];
+    const int klast = kbeg + ((kend - kbeg - 1) / BK) * BK;
+    auto fetch = [&](auto slot_c, int k0) {
+        constexpr int sl = decltype(slot_c)::value;
+        k0 = k0 < klast ? k0 : klast;
+        if (LA == KC) load_tile_kc4<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra4[sl], tid);
+        else load_tile_ic8<TM, true>(g.A, g.lda, i0, g.MI, k0, kend, ra8[sl], tid);
+        if (LB == KC) load_tile_kc4<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4[sl], tid);
+        else load_tile_ic8<TN, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8[sl], tid);
     };
     unsigned pka[12 * TM], pkb[12 * TN];
-    // PRO: k-contiguous A (forward): prologue over k; idx-contiguous A and B (weight gradient): prologue on B over ITS idx
-    constexpr bool PROB = PRO && LA == IC && LB == IC;
-    float psb = 1.f, ptb = 0.f;
-    if (PROB) {
-        int jb = j0 + tid % (64 * TN);
-        jb = jb < g.NJ ? jb : g.NJ - 1;
-        psb = g.pscale[jb]; ptb = g.pshift[jb];
-    }
-    auto split = [&](int k0) {
-        if (LA == KC) split_tile_kc4<PRO, TM, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
-        else split_tile_ic8<TM, NP>(ra8, pka);
-        if (LB == KC) split_tile_kc4<false, TN, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
-        else split_tile_ic8<TN, NP, PROB>(rb8, pkb, psb, ptb);
+    auto split = [&](auto slot_c, int k0) {
+        constexpr int sl = decltype(slot_c)::value;
+        k0 = k0 < klast ? k0 : klast;
+        if (LA == KC) split_tile_kc4<PRO, TM, NP>(ra4[sl], pka, tid, k0, g.pscale, g.pshift);
+        else split_tile_ic8<TM, NP>(ra8[sl], pka);
+        if (LB == KC) split_tile_kc4<false, TN, NP>(rb4[sl], pkb, tid, k0, nullptr, nullptr);
+        else split_tile_ic8<TN, NP>(rb8[sl], pkb);
     };
     auto write = [&]() {
         if (LA == KC) write_tile_kc4<TM, NP>(sA, pka, tid);
@@ -692,165 +587,39 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
             return;
         }
         // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-        constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB, PA3[3] = FACL_SB3_PA, PB3[3] = FACL_SB3_PB;
+        constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
 #pragma unroll
-        for (int t = 0; t < (NP == 3 ? 6 : 3); ++t)
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][NP == 3 ? PA[t] : PA3[t]], bf[b][NP == 3 ? PB[t] : PB3[t]], acc[a][b]);
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA_BF16(af[a][NP == 3 ? PA[t] : 0], bf[b][NP == 3 ? PB[t] : 0], acc[a][b]);
     };
-    fetch(kbeg);
-    split(kbeg);
+    auto for_slots = [&](auto&& f) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, DEPTH>{});
+    };
+    for_slots([&](auto sc) { fetch(sc, kbeg + decltype(sc)::value * BK); });
+    split(std::integral_constant<int, 0>{}, kbeg);
     write();
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        // the next stage (the last step re-reads its own tile: harmless, keeps the loop body one straight block)
-        const int kn = (k0 + BK < kend) ? k0 + BK : k0;
-        fetch(kn);
-        __builtin_amdgcn_sched_barrier(0);                             // all loads in flight before the MFMAs
-        mfma_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block(1);
-        split(kn);                                                     // VALU work for the scheduler to sink into the MFMA shadow
-        __syncthreads();                                               // every wave has read this stage
-        write();
-        __syncthreads();
+    for (int kg = kbeg; kg < kend; kg += DEPTH * BK) {
+        for_slots([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int k0 = kg + u * BK;
+            if (k0 < kend) {
+                fetch(uc, k0 + DEPTH * BK);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block(1);
+                split(std::integral_constant<int, (u + 1) % DEPTH>{}, k0 + BK);
+                __syncthreads();
+                write();
+                __syncthreads();
+            }
+        });
     }
-    if constexpr (NP == 1) gemm_epilogue_h<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
-    else gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
-}
-
-// ---- small problems: split-K INSIDE the workgroup ---------------------------------------------------------------------------
-// A 64x64-tile GEMM whose grid is one wave of workgroups (the FC head: 800 or 80 rows) is a serial chain of K/32
-// stages per workgroup at ~0.75 us each (split -> LDS -> 12 dependent MFMAs, measured: 4 us + 0.75 us per stage,
-// independent of M and N), i.e. pure latency.  Here KG groups of 4 waves take every KG-th stage of the SAME output tile,
-// each with its own LDS image, and the partial tiles meet in LDS in fixed group order (deterministic); group 0 runs the
-// ordinary epilogue, so bias / statistics / centre term keep working and no slice buffer or second kernel is needed.
-template <int LA, int LB, bool PRO, int NP, int KG>
-__global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
-    constexpr int PL = 64 * SBROW;                                      // one plane of one operand (elements)
-    constexpr int TILE_F = NP * 2 * PL * 2 / 4;                         // both operand images of a group, in floats
-    constexpr int STG = 4 * 32 * 36;                                    // epilogue staging of group 0 (floats)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
-    const int wr = wave >> 1, wc = wave & 1;
-    unsigned short* const sA = reinterpret_cast<unsigned short*>(smem + grp * TILE_F);
-    unsigned short* const sB = sA + NP * PL;
-    const TileId tile = xcd_tile();
-    const int i0 = tile.y * 64, j0 = tile.x * 64;
-    const int kbeg = tile.z * g.kchunk;
-    const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
-    const int nst = (kend - kbeg + BK - 1) / BK, nit = (nst + KG - 1) / KG;
-
-    f32x16 acc[1][1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-
-    float4 ra4[2], rb4[2];
-    float ra8[8], rb8[8];
-    auto fetch = [&](int k0) {
-        if (k0 + BK <= kend) {                                         // wave-uniform
-            if (LA == KC) load_tile_kc4<1, true>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
-            else load_tile_ic8<1, true>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
-            if (LB == KC) load_tile_kc4<1, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
-            else load_tile_ic8<1, true>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
-        } else {
-            if (LA == KC) load_tile_kc4<1, false>(g.A, g.lda, i0, g.MI, k0, kend, ra4, tid);
-            else load_tile_ic8<1, false>(g.A, g.lda, i0, g.MI, k0, kend, ra8, tid);
-            if (LB == KC) load_tile_kc4<1, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb4, tid);
-            else load_tile_ic8<1, false>(g.B, g.ldb, j0, g.NJ, k0, kend, rb8, tid);
-        }
-    };
-    unsigned pka[12], pkb[12];
-    auto split = [&](int k0) {
-        if (LA == KC) split_tile_kc4<PRO, 1, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
-        else split_tile_ic8<1, NP>(ra8, pka);
-        if (LB == KC) split_tile_kc4<false, 1, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
-        else split_tile_ic8<1, NP>(rb8, pkb);
-    };
-    auto write = [&]() {
-        if (LA == KC) write_tile_kc4<1, NP>(sA, pka, tid);
-        else write_tile_ic8<1, NP>(sA, pka, tid);
-        if (LB == KC) write_tile_kc4<1, NP>(sB, pkb, tid);
-        else write_tile_ic8<1, NP>(sB, pkb, tid);
-    };
-    auto mfma_block = [&](int kk) {
-        bf16x8 af[NP], bf[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            af[p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + (32 * wr + q) * SBROW + 16 * kk + 8 * h);
-            bf[p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + (32 * wc + q) * SBROW + 16 * kk + 8 * h);
-        }
-        if constexpr (NP == 1) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]),
-                                                               acc[0][0], 0, 0, 0);
-        } else {
-            constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB, PA3[3] = FACL_SB3_PA, PB3[3] = FACL_SB3_PB;
-#pragma unroll
-            for (int t = 0; t < (NP == 3 ? 6 : 3); ++t)
-                acc[0][0] = MFMA_BF16(af[NP == 3 ? PA[t] : PA3[t]], bf[NP == 3 ? PB[t] : PB3[t]], acc[0][0]);
-        }
-    };
-    // stage s of the chunk belongs to group s % KG; a group that runs out of stages re-stages its last one (harmless)
-    // and skips the MFMAs, so that every wave reaches every barrier
-    auto kof = [&](int it) {
-        int s = grp + KG * it;
-        s = s < nst ? s : nst - 1;
-        return kbeg + s * BK;
-    };
-    { const int k0 = kof(0); fetch(k0); split(k0); write(); }
-    __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        const int kn = kof(it + 1 < nit ? it + 1 : it);
-        fetch(kn);
-        if (grp + KG * it < nst) {                                     // wave-uniform
-            mfma_block(0);
-            mfma_block(1);
-        }
-        split(kn);
-        __syncthreads();
-        write();
-        __syncthreads();
-    }
-    // partial tiles -> LDS (behind group 0's staging area), summed by group 0 in group order
-    float* red = smem + STG;
-    if (grp > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(grp - 1) * 4096 + wave * 1024 + r * 64 + lane] = acc[0][0][r];
-    }
-    __syncthreads();
-    if (grp > 0) return;
-#pragma unroll
-    for (int gg = 0; gg < KG - 1; ++gg)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[gg * 4096 + wave * 1024 + r * 64 + lane];
-    gemm_epilogue<1, 1>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
-}
-
-constexpr int SBK_KG = 4;
-template <int LA, int LB, bool PRO, int NP>
-int launch_sbk(const GemmArgs& g, int nz, hipStream_t st) {
-    constexpr int TILE_F = NP * 2 * 64 * SBROW * 2 / 4, STG = 4 * 32 * 36;
-    constexpr int F = SBK_KG * TILE_F > STG + (SBK_KG - 1) * 4096 ? SBK_KG * TILE_F : STG + (SBK_KG - 1) * 4096;
-    constexpr int lds = F * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
-    hipLaunchKernelGGL((k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>), grid, dim3(256 * SBK_KG), lds, st, g);
-    return facl_launch_status();
-}
-// one wave of 64x64 workgroups and enough stages to share out
-static inline bool sbk_fits(const GemmArgs& g, int nz) {
-    static const int off = getenv("FACL_GEMM_NOSBK") ? atoi(getenv("FACL_GEMM_NOSBK")) : 0;
-    const long long t64 = (long long)((g.NJ + 63) / 64) * ((g.MI + 63) / 64) * nz;
-    return !off && t64 <= 320 && g.kchunk >= 2 * SBK_KG * BK;
+    gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
 }
 
 // sum over split-K slices: out[e] = sum_z part[z][e], slices added in order (deterministic); four slice loads in flight
@@ -877,24 +646,6 @@ __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n
     }
 }
 
-template <int LA, int LB, bool PRO, int NP>
-int launch_sb_np(const GemmArgs& g, int nz, long long big, hipStream_t st, int* rows_per_part) {
-    if (sbk_fits(g, nz)) {
-        if (rows_per_part) *rows_per_part = 32;
-        return launch_sbk<LA, LB, PRO, NP>(g, nz, st);
-    }
-    if (big >= 256) {
-        dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
-        hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2, NP>), grid, dim3(256), 0, st, g);
-        if (rows_per_part) *rows_per_part = 64;
-    } else {
-        dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
-        hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1, NP>), grid, dim3(256), 0, st, g);
-        if (rows_per_part) *rows_per_part = 32;
-    }
-    return facl_launch_status();
-}
-
 // tile choice: 128x128 blocks when they already fill the chip, else 64x64 blocks (4x the workgroups) -- the FC head
 // (M = 768 or 32 rows) would otherwise run on 48 or 8 of the 256 CUs
 template <int LA, int LB, bool PRO>
@@ -903,20 +654,26 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     static const int use_dma = getenv("FACL_GEMM_DMA") ? atoi(getenv("FACL_GEMM_DMA")) : 1;
     // FACL_GEMM_F32=1 selects the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split-bf16 ones
     static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
-    if (g.prec == 1) return launch_sb_np<LA, LB, PRO, 1>(g, nz, big, st, rows_per_part);   // fp16-input MFMA, fp32 accumulation
-    if (g.prec == 2) return launch_sb_np<LA, LB, PRO, 2>(g, nz, big, st, rows_per_part);   // bf16x3 (opt-in)
-    if (!use_f32) {
-        if (sbk_fits(g, nz)) {
+    if (g.prec == 1) {                                                  // fp16-input MFMA, fp32 accumulation
+        if (big >= 256) {
+            dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2, 1>), grid, dim3(256), 0, st, g);
+            if (rows_per_part) *rows_per_part = 64;
+        } else {
+            dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1, 1>), grid, dim3(256), 0, st, g);
             if (rows_per_part) *rows_per_part = 32;
-            return launch_sbk<LA, LB, PRO, 3>(g, nz, st);
         }
+        return facl_launch_status();
+    }
+    if (!use_f32) {
         if (big >= 256) {
             dim3 grid((g.NJ + 127) / 128, (g.MI + 127) / 128, nz);
             hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 2, 2>), grid, dim3(256), 0, st, g);
             if (rows_per_part) *rows_per_part = 64;
         } else {
             dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
-            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1>), grid, dim3(256), 0, st, g);
+            hipLaunchKernelGGL((k_gemm_sb<LA, LB, PRO, 1, 1, 3, 4>), grid, dim3(256), 0, st, g);
             if (rows_per_part) *rows_per_part = 32;
         }
         return facl_launch_status();
@@ -954,12 +711,6 @@ static int gemm_fwd_p(const float* a, int64_t M, int K, const float* W, int ldw,
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, pscale, pshift, centers, Wc, ldwc,
                sums ? (double*)ws : nullptr, K, nullptr, nullptr, nullptr, prec};
     int rpp = 64;
-    if (sums) {                                                        // the statistics partials must fit BEFORE anything is written
-        const long long big = (long long)((N + 127) / 128) * ((M + 127) / 128);
-        const int rpp0 = (big >= 256 && !sbk_fits(g, 1)) ? 64 : 32;
-        const long long prow0 = ((M + 2 * rpp0 - 1) / (2 * rpp0)) * 2;
-        if ((size_t)prow0 * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
-    }
     int rc = pscale ? launch<KC, KC, true>(g, 1, st, &rpp) : launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
     const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
@@ -982,7 +733,6 @@ static int gemm_fwd_segmax_p(const float* a, int64_t M, int K, const float* W, i
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, nullptr, nullptr, nullptr, nullptr, 0,
                sums ? (double*)ws : nullptr, K, sgn, ymax, arg, prec};
     int rpp = 64;
-    if (sums && (size_t)(((M + 127) / 128) * 2) * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     int rc = launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
     const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
@@ -1005,10 +755,6 @@ static int gemm_wgrad_p(const float* dy, const float* a, int64_t M, int N, int K
     if (!dy || !a || !dW || !slices) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    {   // few rows (the FC head): the workgroup splits the contraction itself and writes dW directly, no slices
-        GemmArgs g1{dy, N, a, lda, dW, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (int)M, nullptr, nullptr, nullptr, prec};
-        if (M <= 8192 && sbk_fits(g1, 1)) return launch<IC, IC, false>(g1, 1, st, nullptr);
-    }
     int kchunk = (int)((M + nz - 1) / nz);
     kchunk = (kchunk + BK - 1) / BK * BK;
     nz = (int)((M + kchunk - 1) / kchunk);
@@ -1019,43 +765,6 @@ static int gemm_wgrad_p(const float* dy, const float* a, int64_t M, int N, int K
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_sum_slices, dim3(grid), dim3(256), 0, st, slices, nz, n4, dW);
     return facl_launch_status();
-}
-
-// dW (N,K) = dy^T (N,M) relu(pscale * y + pshift) (M,K): the weight gradient of a layer whose input activation is the
-// BatchNorm + ReLU of the previous layer's raw output y -- recomputed while the tile is staged, never materialised
-// (the forward does the same in its prologue: csrc/gemm_rs.hip).  Large row counts only (the 128x128-tile kernel):
-// FACL_E_CONFIG otherwise, callers then materialise the activation and use facl_gemm_wgrad.
-static int gemm_wgrad_pro_p(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
-                            const float* pshift, float* dW, float* slices, int nz, void* stream, int prec) {
-    if (!dy || !y || !pscale || !pshift || !dW || !slices) return FACL_E_NULL;
-    if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
-    static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
-    if (use_f32 || prec == 1) return FACL_E_CONFIG;
-    hipStream_t st = (hipStream_t)stream;
-    int kchunk = (int)((M + nz - 1) / nz);
-    kchunk = (kchunk + BK - 1) / BK * BK;
-    nz = (int)((M + kchunk - 1) / kchunk);
-    GemmArgs g{dy, N, y, ldy, slices, K, N, K, (int)M, nullptr, pscale, pshift, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr, prec};
-    const long long big = (long long)((K + 127) / 128) * ((N + 127) / 128) * nz;
-    if (big < 256 || sbk_fits(g, nz)) return FACL_E_CONFIG;
-    dim3 grid((K + 127) / 128, (N + 127) / 128, nz);
-    if (prec == 2) hipLaunchKernelGGL((k_gemm_sb<IC, IC, true, 2, 2, 2>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((k_gemm_sb<IC, IC, true, 2, 2, 3>), grid, dim3(256), 0, st, g);
-    int rc = facl_launch_status();
-    if (rc) return rc;
-    const long long n4 = (long long)N * K / 4;
-    const int rgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_sum_slices, dim3(rgrid), dim3(256), 0, st, slices, nz, n4, dW);
-    return facl_launch_status();
-}
-
-extern "C" int facl_gemm_wgrad_pro(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
-                                   const float* pshift, float* dW, float* slices, int nz, void* stream) {
-    return gemm_wgrad_pro_p(dy, y, M, N, K, ldy, pscale, pshift, dW, slices, nz, stream, 0);
-}
-extern "C" int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
-                                      const float* pshift, float* dW, float* slices, int nz, void* stream) {
-    return gemm_wgrad_pro_p(dy, y, M, N, K, ldy, pscale, pshift, dW, slices, nz, stream, 2);
 }
 
 // ---- C ABI: fp32-result entries and their fp16-input twins (same arguments; inputs rounded to fp16 while staged, one
@@ -1093,23 +802,4 @@ extern "C" int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N
 extern "C" int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                                    float* slices, int nz, void* stream) {
     return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 1);
-}
-
-// ---- "bf16x3" twins (opt-in precision "x3": two bf16 pieces per operand, three products; common.h) -------------------------
-extern "C" int facl_gemm_fwd_x3(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
-                                const float* pscale, const float* pshift, const float* centers, const float* Wc,
-                                int ldwc, float* y, double* sums, void* ws, void* stream) {
-    return gemm_fwd_p(a, M, K, W, ldw, N, bias, pscale, pshift, centers, Wc, ldwc, y, sums, ws, stream, 2);
-}
-extern "C" int facl_gemm_fwd_segmax_x3(const float* a, int64_t M, int K, const float* W, int ldw, int N, const float* bias,
-                                       const float* sgn, float* y, double* sums, float* ymax, int32_t* arg, void* ws,
-                                       void* stream) {
-    return gemm_fwd_segmax_p(a, M, K, W, ldw, N, bias, sgn, y, sums, ymax, arg, ws, stream, 2);
-}
-extern "C" int facl_gemm_dgrad_x3(const float* dy, int64_t M, int N, const float* W, int ldw, int K, float* da, void* stream) {
-    return gemm_dgrad_p(dy, M, N, W, ldw, K, da, stream, 2);
-}
-extern "C" int facl_gemm_wgrad_x3(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
-                                  float* slices, int nz, void* stream) {
-    return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 2);
 }

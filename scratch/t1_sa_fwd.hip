@@ -1,0 +1,536 @@
+// Set-abstraction point-MLP, forward (net3DV_1: cn3d_model_conbag.py:43-58 / :162-177):
+//   3 x [1x1 conv -> BatchNorm2d -> ReLU]  D -> 64 -> 64 -> 256, then max over the K neighbours.
+//
+// Train-mode BN needs the statistics of every layer over ALL positions before that layer's ReLU,
+// so the forward is a short pipeline of passes; nothing wider than 64 channels ever reaches HBM:
+//   facl_sa_x_moments : sum x, sum x x^T  (BN1 statistics follow analytically: y1 is affine in x)
+//   facl_sa_fwd2      : x -> a1 (VALU) -> y2 = a1 W2^T + b2 (MFMA) ; stores y2 ("fragment layout"),
+//                       accumulates sum / sumsq of y2
+//   facl_sa_fwd3      : y2 -> a2 -> y3 = a2 W3^T + b3 (MFMA) ; accumulates sum / sumsq of y3 and
+//                       keeps only max_k (sgn*y3) + argmax per (group, channel): BN+ReLU are monotone
+//                       per channel, so pooled = relu(|scale| * max(sgn*y3) + shift), sgn = sign(gamma)
+//   facl_sa_pool      : that last elementwise step.
+// Eval mode runs fwd2 + fwd3 + pool with constants folded from the running statistics.
+//
+// A "unit" is 64 consecutive positions (= one group when K = 64).  One wave owns one unit at a time.
+// Roofline: MFMA fp32 (157.3 TFLOP/s).  FLOPs per unit: fwd2 2*64*64*64, fwd3 2*64*64*256.
+#include "common.h"
+#include <stdlib.h>
+
+int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+
+namespace {
+
+constexpr int SA_GRID = 256;   // one workgroup per CU; waves grid-stride over the units
+
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, long long P,
+                                                   double* __restrict__ part) {
+    constexpr int V = D + D * D;
+    double acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        float v[D];
+        if (D == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + p * 4);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[D - 1] = t.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = x[p * D + i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            acc[i] += (double)v[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc[D + i * D + j] += (double)v[i] * (double)v[j];
+        }
+    }
+    const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const double s = wave_sum_f64(acc[i]);
+        if (lane_id() == 0) part[(size_t)wave_g * V + i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fwd2: transposed orientation  D2^T[c2][p] = sum_k W2[c2][k] a1[p][k]  so that the result
+// registers are (lane = position, register = channel) = the fragment layout.
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_sa_fwd2(const float* __restrict__ x, int nunits,
+                                                 const float* __restrict__ l1tab_g, const float* __restrict__ W2,
+                                                 const float* __restrict__ b2, float* __restrict__ y2f,
+                                                 double* __restrict__ part) {
+    __shared__ float4 w2f[2 * 8 * 64];      // A fragments of W2: [rt][s4][lane] -> W2[32rt+q][32h+4s4 .. +3]
+    __shared__ float4 l1tab[64 * 2];        // folded layer 1: [c][w0 w1 w2 w3 | b 0 0 0]
+    __shared__ float4 b2s[16];
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int ln = i & 63, s4 = (i >> 6) & 7, rt = i >> 9;
+        w2f[i] = *reinterpret_cast<const float4*>(W2 + (32 * rt + (ln & 31)) * 64 + 32 * (ln >> 5) + 4 * s4);
+    }
+    if (threadIdx.x < 128) l1tab[threadIdx.x] = reinterpret_cast<const float4*>(l1tab_g)[threadIdx.x];
+    if (threadIdx.x < 16) b2s[threadIdx.x] = reinterpret_cast<const float4*>(b2)[threadIdx.x];
+    __syncthreads();
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+
+    float ps[2][16], pq[2][16];            // per-lane partial sum / sumsq of y2, channel = 32rt+rowmap(r,h)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ps[rt][r] = 0.f; pq[rt][r] = 0.f; }
+
+    // software prefetch: with one wave per SIMD the HBM latency of the next unit's input is otherwise exposed
+    auto load_x = [&](int u, float (&xv)[2][4]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const size_t p = (size_t)u * 64 + 32 * ct + q;
+            if (D == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(x + p * 4);
+                xv[ct][0] = t.x; xv[ct][1] = t.y; xv[ct][2] = t.z; xv[ct][3] = t.w;
+            } else {
+                xv[ct][0] = x[p * 3]; xv[ct][1] = x[p * 3 + 1]; xv[ct][2] = x[p * 3 + 2]; xv[ct][3] = 0.f;
+            }
+        }
+    };
+    float xn[2][4];
+    if (wave_g < nunits) load_x(wave_g, xn);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        asm volatile("" ::: "memory");       // LDS tables are re-read per unit instead of living in registers
+        float xv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[ct][i] = xn[ct][i];
+        if (u + nwaves < nunits) load_x(u + nwaves, xn);
+        // layer 1 on the VALU: this lane's two positions x the 32 channels of its half
+        float a1[2][32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float4 w = l1tab[(32 * h + s) * 2];
+            const float b = l1tab[(32 * h + s) * 2 + 1].x;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                float v = fmaf(w.x, xv[ct][0], b);
+                v = fmaf(w.y, xv[ct][1], v);
+                v = fmaf(w.z, xv[ct][2], v);
+                if (D == 4) v = fmaf(w.w, xv[ct][3], v);
+                a1[ct][s] = fmaxf(v, 0.f);
+            }
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 bb = b2s[8 * rt + 2 * r4 + h];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[rt][ct][4 * r4 + 0] = bb.x; acc[rt][ct][4 * r4 + 1] = bb.y;
+                    acc[rt][ct][4 * r4 + 2] = bb.z; acc[rt][ct][4 * r4 + 3] = bb.w;
+                }
+            }
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const float4 f0 = w2f[(0 * 8 + s4) * 64 + lane];
+            const float4 f1 = w2f[(1 * 8 + s4) * 64 + lane];
+            const float fa0[4] = {f0.x, f0.y, f0.z, f0.w};
+            const float fa1[4] = {f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = MFMA32(fa0[e], a1[0][4 * s4 + e], acc[0][0]);
+                acc[0][1] = MFMA32(fa0[e], a1[1][4 * s4 + e], acc[0][1]);
+                acc[1][0] = MFMA32(fa1[e], a1[0][4 * s4 + e], acc[1][0]);
+                acc[1][1] = MFMA32(fa1[e], a1[1][4 * s4 + e], acc[1][1]);
+            }
+        }
+        float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 v = make_float4(acc[rt][ct][4 * r4], acc[rt][ct][4 * r4 + 1],
+                                                 acc[rt][ct][4 * r4 + 2], acc[rt][ct][4 * r4 + 3]);
+                    *reinterpret_cast<float4*>(tile + (((ct * 2 + rt) * 4 + r4) * 64 + lane) * 4) = v;
+                }
+        if (part) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v0 = acc[rt][0][r], v1 = acc[rt][1][r];
+                    ps[rt][r] += v0 + v1;
+                    pq[rt][r] = fmaf(v0, v0, fmaf(v1, v1, pq[rt][r]));
+                }
+        }
+    }
+    if (part) {
+        // reduce over the 32 positions-lanes of each half in fp64; lane q == 0 of each half writes
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double s = ps[rt][r], sq = pq[rt][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); sq += __shfl_xor(sq, o, 64); }
+                if (q == 0) {
+                    const int c = 32 * rt + rowmap(r, h);
+                    part[(size_t)wave_g * 128 + 2 * c] = s;
+                    part[(size_t)wave_g * 128 + 2 * c + 1] = sq;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fwd3: normal orientation  D3[p][c3] = sum_k a2[p][k] W3'[c3][k]  (lane = channel, registers =
+// positions), so BN statistics and the max over the group's positions are in-lane reductions.
+__device__ unsigned long long g_dbg[8];
+__global__ __launch_bounds__(512) void k_sa_fwd3(const float* __restrict__ y2f, int nunits,
+                                                 const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                 const float* __restrict__ W3, const float* __restrict__ b3,
+                                                 const float* __restrict__ sgn3, float* __restrict__ ymax,
+                                                 unsigned char* __restrict__ arg, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    float4* w3f = lds4;                      // B fragments of sgn*W3: [ct3][rt][r4][lane] (64 KiB)
+    float4* sc2s = lds4 + 4096;              // 16
+    float4* sh2s = sc2s + 16;                // 16
+    float* b3s = reinterpret_cast<float*>(sh2s + 16);   // 256
+    // per-wave, per-lane fp64 (sum, sumsq) of y3 for each column tile: kept in LDS so that the
+    // column-tile loop can stay a real loop (registers: a2 64 + acc 32 instead of 8 unrolled tiles)
+    double2* stat = reinterpret_cast<double2*>(b3s + 256) + (threadIdx.x >> 6) * 512;   // [ct3][lane]
+    for (int i = threadIdx.x; i < 4096; i += 512) {
+        const int ln = i & 63, r4 = (i >> 6) & 3, rt = (i >> 8) & 1, ct3 = i >> 9;
+        const int c3 = 32 * ct3 + (ln & 31);
+        float4 w = *reinterpret_cast<const float4*>(W3 + c3 * 64 + 32 * rt + 8 * r4 + 4 * (ln >> 5));
+        const float s = sgn3[c3];
+        w.x *= s; w.y *= s; w.z *= s; w.w *= s;
+        w3f[i] = w;
+    }
+    if (threadIdx.x < 16) {
+        sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
+        sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
+    }
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn3[threadIdx.x];
+    __syncthreads();
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 8 + (threadIdx.x >> 6), nwaves = gridDim.x * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stat[i * 64 + lane] = make_double2(0.0, 0.0);
+
+    const unsigned long long t_all = __builtin_amdgcn_s_memtime(), t_rt = __builtin_readcyclecounter();
+    float4 yn[16];
+    auto issue_loads = [&](int u) {
+        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
+    };
+    if (wave_g < nunits) issue_loads(wave_g);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        float a2[2][2][16];                   // [pt][rt][r] = a2[p = 32pt+q][k = 32rt+rowmap(r,h)]
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 y = yn[(ct * 2 + rt) * 4 + r4];
+                    const float4 sc = sc2s[8 * rt + 2 * r4 + h], sh = sh2s[8 * rt + 2 * r4 + h];
+                    a2[ct][rt][4 * r4 + 0] = fmaxf(fmaf(sc.x, y.x, sh.x), 0.f);
+                    a2[ct][rt][4 * r4 + 1] = fmaxf(fmaf(sc.y, y.y, sh.y), 0.f);
+                    a2[ct][rt][4 * r4 + 2] = fmaxf(fmaf(sc.z, y.z, sh.z), 0.f);
+                    a2[ct][rt][4 * r4 + 3] = fmaxf(fmaf(sc.w, y.w, sh.w), 0.f);
+                }
+        if (u + nwaves < nunits) issue_loads(u + nwaves);
+#pragma unroll 1
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            const float bias = b3s[32 * ct3 + q];
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = bias; }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 f = w3f[((ct3 * 2 + rt) * 4 + r4) * 64 + lane];
+                    const float fb[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = MFMA32(a2[0][rt][4 * r4 + e], fb[e], acc0);
+                        acc1 = MFMA32(a2[1][rt][4 * r4 + e], fb[e], acc1);
+                    }
+                }
+            float s = 0.f, sq = 0.f, best = acc0[0];
+            int bp = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc0[r];
+                s += v; sq = fmaf(v, v, sq);
+                if (v > best) { best = v; bp = rowmap(r, 0); }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc1[r];
+                s += v; sq = fmaf(v, v, sq);
+                if (v > best) { best = v; bp = 32 + rowmap(r, 0); }
+            }
+            bp += 4 * h;
+            const float ob = __shfl_xor(best, 32, 64);
+            const int op = __shfl_xor(bp, 32, 64);
+            if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }   // first max wins (MaxPool2d)
+            if (part) {
+                double2 st = stat[ct3 * 64 + lane];
+                st.x += (double)s; st.y += (double)sq;
+                stat[ct3 * 64 + lane] = st;
+            }
+            if (h == 0) {
+                ymax[(size_t)u * 256 + 32 * ct3 + q] = best;
+                arg[(size_t)u * 256 + 32 * ct3 + q] = (unsigned char)bp;
+            }
+        }
+    }
+    if (lane == 0) { atomicAdd(&g_dbg[3], __builtin_amdgcn_s_memtime() - t_all); atomicAdd(&g_dbg[4], 1ull); atomicAdd(&g_dbg[5], __builtin_readcyclecounter() - t_rt); }
+    if (part) {
+#pragma unroll
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            const double2 st = stat[ct3 * 64 + lane];
+            const double s = st.x + __shfl_xor(st.x, 32, 64);
+            const double sq = st.y + __shfl_xor(st.y, 32, 64);
+            if (h == 0) {
+                part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = s;
+                part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = sq;
+            }
+        }
+    }
+}
+
+// Split-bf16 (bf16x6, common.h) version of fwd3: same tiling, same epilogue, same outputs; the 64x64 a2 tile of a
+// unit never leaves the wave's registers -- the fragment-layout float4s of y2 already hold 4 consecutive channels of
+// one position, so two of them give the 8 k-slots of a 32x32x16 A operand (slot (h,j) of block kk <-> channel
+// 16kk + 4h + j for j < 4, 16kk + 8 + 4h + (j-4) else; W3's B fragments use the same map).  Per unit and wave:
+// 64 values/lane split into 3 bf16 planes (96 VGPRs), 96 ds_read_b128 of pre-split sgn*W3 fragments, 384 MFMAs.
+// Roofline: MFMA bf16 (2.5 PFLOP/s dense); 6 * 2*64*64*256 executed FLOP per unit.
+__global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2f, int nunits,
+                                                    const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                    const float* __restrict__ W3, const float* __restrict__ b3,
+                                                    const float* __restrict__ sgn3, float* __restrict__ ymax,
+                                                    unsigned char* __restrict__ arg, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    uint4* w3p = reinterpret_cast<uint4*>(lds4);         // [(ct3*4 + kk)*3 + plane][lane]: 96 KiB
+    float4* sc2s = lds4 + 6144;              // 16
+    float4* sh2s = sc2s + 16;                // 16
+    float* b3s = reinterpret_cast<float*>(sh2s + 16);   // 256
+    // per-wave fp64 (sum, sumsq) of y3 per channel: [ct3][q] (the two lane halves are merged before the update)
+    double2* stat = reinterpret_cast<double2*>(b3s + 256) + (threadIdx.x >> 6) * 256;
+    for (int i = threadIdx.x; i < 2048; i += 512) {
+        const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
+        const int c3 = 32 * ct3 + (ln & 31);
+        const float* wrow = W3 + c3 * 64 + 16 * kk + 4 * (ln >> 5);
+        float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
+        const float s = sgn3[c3];
+        unsigned hi[4], mi[4], lo[4];
+        split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
+        split_pair(w0.z * s, w0.w * s, hi[1], mi[1], lo[1]);
+        split_pair(w1.x * s, w1.y * s, hi[2], mi[2], lo[2]);
+        split_pair(w1.z * s, w1.w * s, hi[3], mi[3], lo[3]);
+        uint4* d = w3p + ((ct3 * 4 + kk) * 3) * 64 + ln;
+        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    if (threadIdx.x < 16) {
+        sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
+        sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
+    }
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn3[threadIdx.x];
+    __syncthreads();
+
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31;
+    const int wave_g = blockIdx.x * 8 + (threadIdx.x >> 6), nwaves = gridDim.x * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stat[i * 64 + lane] = make_double2(0.0, 0.0);
+
+    float4 yn[16];
+    auto issue_loads = [&](int u) {
+        const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
+    };
+    if (wave_g < nunits) issue_loads(wave_g);
+    for (int u = wave_g; u < nunits; u += nwaves) {
+        bf16x8 ap[2][4][3];                  // [position tile][k16 block][plane]
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rt = kk >> 1, m = kk & 1;
+                unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
+                    const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
+                    split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
+                    split_pair(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1], lo[2 * t + 1]);
+                }
+                ap[ct][kk][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
+                ap[ct][kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
+                ap[ct][kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+            }
+        if (u + nwaves < nunits) issue_loads(u + nwaves);
+#pragma unroll 1
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            const float bias = b3s[32 * ct3 + q];
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = bias; }
+            constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 bfr[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, w3p[((ct3 * 4 + kk) * 3 + p) * 64 + lane]);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc0 = MFMA_BF16(ap[0][kk][PA[t]], bfr[PB[t]], acc0);
+                    acc1 = MFMA_BF16(ap[1][kk][PA[t]], bfr[PB[t]], acc1);
+                }
+            }
+            float s = 0.f, sq = 0.f, best = acc0[0];
+            int bp = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc0[r];
+                s += v; sq = fmaf(v, v, sq);
+                if (v > best) { best = v; bp = rowmap(r, 0); }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc1[r];
+                s += v; sq = fmaf(v, v, sq);
+                if (v > best) { best = v; bp = 32 + rowmap(r, 0); }
+            }
+            bp += 4 * h;
+            const float ob = __shfl_xor(best, 32, 64);
+            const int op = __shfl_xor(bp, 32, 64);
+            if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }   // first max wins (MaxPool2d)
+            if (part) {
+                const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+                if (h == 0) {
+                    double2 d = stat[ct3 * 32 + q];
+                    d.x += (double)st; d.y += (double)sqt;
+                    stat[ct3 * 32 + q] = d;
+                }
+            }
+            if (h == 0) {
+                ymax[(size_t)u * 256 + 32 * ct3 + q] = best;
+                arg[(size_t)u * 256 + 32 * ct3 + q] = (unsigned char)bp;
+            }
+        }
+    }
+    if (part && h == 0) {
+#pragma unroll
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            const double2 st = stat[ct3 * 32 + q];
+            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x;
+            part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = st.y;
+        }
+    }
+}
+
+__global__ void k_sa_pool(const float* __restrict__ ymax, long long n4, int C4, const float* __restrict__ scale,
+                          const float* __restrict__ shift, float* __restrict__ pooled) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int c4 = (int)(i % C4);
+        const float4 y = reinterpret_cast<const float4*>(ymax)[i];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
+        const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
+        float4 o;
+        o.x = fmaxf(fmaf(fabsf(sc.x), y.x, sh.x), 0.f);
+        o.y = fmaxf(fmaf(fabsf(sc.y), y.y, sh.y), 0.f);
+        o.z = fmaxf(fmaf(fabsf(sc.z), y.z, sh.z), 0.f);
+        o.w = fmaxf(fmaf(fabsf(sc.w), y.w, sh.w), 0.f);
+        reinterpret_cast<float4*>(pooled)[i] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int facl_debug_counters(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 8 * sizeof(unsigned long long));
+}
+
+extern "C" int facl_sa_x_moments(const float* x, int64_t P, int D, double* mom, void* ws, void* stream) {
+    if (!x || !mom || !ws) return FACL_E_NULL;
+    if ((D != 3 && D != 4) || P < 1) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = 512, V = D + D * D;       // 512 blocks x 4 waves = 2048 partial rows
+    if (D == 4) hipLaunchKernelGGL((k_x_moments<4>), dim3(grid), dim3(256), 0, st, x, (long long)P, (double*)ws);
+    else hipLaunchKernelGGL((k_x_moments<3>), dim3(grid), dim3(256), 0, st, x, (long long)P, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, grid * 4, V, mom, st);
+}
+
+extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* l1tab, const float* W2,
+                            const float* b2, float* y2f, double* sums2, void* ws, void* stream) {
+    if (!x || !l1tab || !W2 || !b2 || !y2f || (sums2 && !ws)) return FACL_E_NULL;
+    if ((D != 3 && D != 4) || nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(nunits < 2 * SA_GRID * 4 ? (nunits + 3) / 4 : 2 * SA_GRID);   // 2 workgroups per CU
+    double* part = sums2 ? (double*)ws : nullptr;
+    if (D == 4) hipLaunchKernelGGL((k_sa_fwd2<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+    else hipLaunchKernelGGL((k_sa_fwd2<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+    int rc = facl_launch_status();
+    if (rc || !sums2) return rc;
+    // waves beyond nunits never enter the loop and still write their (zero) rows
+    return facl_reduce_rows(part, grid * 4, 128, sums2, st);
+}
+
+extern "C" int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
+                            const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
+                            double* sums3, void* ws, void* stream) {
+    if (!y2f || !scale2 || !shift2 || !W3 || !b3 || !sgn3 || !ymax || !arg || (sums3 && !ws)) return FACL_E_NULL;
+    if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 7) / 8 : SA_GRID);
+    // FACL_SA_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one
+    static const int use_f32 = getenv("FACL_SA_F32") ? atoi(getenv("FACL_SA_F32")) : 0;
+    const size_t lds = use_f32 ? (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2)
+                               : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 256 * sizeof(double2);
+    const void* fn = use_f32 ? (const void*)k_sa_fwd3 : (const void*)k_sa_fwd3_sb;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    double* part = sums3 ? (double*)ws : nullptr;
+    if (use_f32)
+        hipLaunchKernelGGL(k_sa_fwd3, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3, ymax,
+                           arg, part);
+    else
+        hipLaunchKernelGGL(k_sa_fwd3_sb, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+                           ymax, arg, part);
+    int rc = facl_launch_status();
+    if (rc || !sums3) return rc;
+    return facl_reduce_rows(part, grid * 8, 512, sums3, st);
+}
+
+extern "C" int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
+                            float* pooled, void* stream) {
+    if (!ymax || !scale || !shift || !pooled) return FACL_E_NULL;
+    if (rows < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
+    const long long n4 = rows * (long long)(C / 4);
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_sa_pool, dim3(grid), dim3(256), 0, (hipStream_t)stream, ymax, n4, C / 4, scale, shift, pooled);
+    return facl_launch_status();
+}

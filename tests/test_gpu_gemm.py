@@ -177,3 +177,84 @@ def test_gemm_x3_twins_within_their_bound(M, K, N):
     sl = _lib.empty(nz * N * K, device=DEV)
     _lib.check(lib.facl_gemm_wgrad_x3(p(dy), p(a), M, N, K, K, p(dW), p(sl), nz, st), "wgrad_x3")
     assert rel_err(dW.cpu().numpy(), (dy.double().t() @ a.double()).cpu().numpy()) < 5e-5
+
+
+def _rs_planes(lib, W, transposed, Wc=None):
+    from facl_amd import _lib
+    N, K = W.shape
+    nb = lib.facl_gemm_rs_planes_bytes(K if transposed else N, N if transposed else K, 1 if Wc is not None else 0)
+    planes = _lib.empty(nb, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.facl_gemm_rs_planes(_lib.ptr(W), W.stride(0), N, K, int(transposed), _lib.ptr(Wc), 3, _lib.ptr(planes),
+                                       _lib.stream()), "rs_planes")
+    return planes
+
+
+@pytest.mark.parametrize("M,K,N,pro,ctr,seg", [(4096, 256, 256, False, True, False), (4096, 256, 512, True, False, False),
+                                               (6144, 512, 1024, True, False, True), (4000, 64, 256, True, True, False),
+                                               (2048 + 96, 128, 512, False, False, False), (49152 // 4, 512, 1024, True, False, True)])
+def test_gemm_rs_fwd_equals_gemm_fwd_and_fp64(M, K, N, pro, ctr, seg):
+    """Row-streamed forward (csrc/gemm_rs.hip: pre-split weight planes through an LDS-DMA ring, activation rows through
+    per-wave slots, BN + ReLU prologue, centre k-step, fused statistics / my_max_pool) vs facl_gemm_fwd[_segmax] on the same
+    inputs -- same arithmetic, so the outputs must agree to the last bit -- and vs an fp64 product.  Ragged row counts
+    (M % 256 != 0, M % 32 != 0) included."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    assert lib.facl_gemm_rs_supported(M, K, N) == 1
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    ps = torch.rand(K, device=DEV, generator=g) + 0.5 if pro else None
+    pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
+    cen = torch.randn(M, 3, device=DEV, generator=g) if ctr else None
+    Wc = torch.randn(N, 3, device=DEV, generator=g).contiguous() if ctr else None
+    sgn = torch.randn(N, device=DEV, generator=g) if seg else None
+    p = _lib.ptr
+    planes = _rs_planes(lib, W, False, Wc)
+    y, sums = _lib.empty(M, N, device=DEV), _lib.empty(N, 2, dtype=torch.float64, device=DEV)
+    ymax = _lib.empty(M // 64, N, device=DEV) if seg else None
+    arg = _lib.empty(M // 64, N, dtype=torch.int32, device=DEV) if seg else None
+    _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax), p(arg),
+                                    p(_ws()), _lib.stream()), "rs_fwd")
+    # reference 1: fp64
+    a64 = a.double()
+    if pro:
+        a64 = torch.relu(a64 * ps.double() + pt.double())
+    ref = a64 @ W.double().t() + b.double()
+    if ctr:
+        ref = ref + cen.double() @ Wc.double().t()
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert rel_err(sums[:, 1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-5
+    assert rel_err(sums[:, 0].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-5 * max(1.0, float(ref.abs().sum(0).max() / ref.sum(0).abs().max()))
+    # fused my_max_pool: exactly the first maximum of sign(sgn) * y over each block of 64 rows of the kernel's own y
+    if seg:
+        sy = (y * torch.where(sgn < 0, -1.0, 1.0)).view(M // 64, 64, N)
+        assert torch.equal(ymax, sy.max(dim=1).values)
+        first = (sy == ymax.unsqueeze(1)).float().argmax(dim=1)
+        assert torch.equal(arg.long(), first)
+    # reference 2: the LDS-staged kernel, same arithmetic -> bit-equal (the centre term is an epilogue FMA there and a
+    # k-step here: with it only to rounding)
+    y2, sums2 = _lib.empty(M, N, device=DEV), _lib.empty(N, 2, dtype=torch.float64, device=DEV)
+    _lib.check(lib.facl_gemm_fwd(p(a), M, K, p(W), K, N, p(b), p(ps), p(pt), p(cen), p(Wc), 3, p(y2), p(sums2), p(_ws()),
+                                 _lib.stream()), "gemm_fwd")
+    if not ctr:
+        assert torch.equal(y, y2)
+    else:
+        assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (8100, 512, 256), (6144, 1024, 512)])
+def test_gemm_rs_dgrad_equals_gemm_dgrad_and_fp64(M, N, K):
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    assert lib.facl_gemm_rs_supported(M, N, K) == 1
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / N ** 0.5
+    planes = _rs_planes(lib, W, True)
+    da, da2 = _lib.empty(M, K, device=DEV), _lib.empty(M, K, device=DEV)
+    _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()), "rs_dgrad")
+    _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, _lib.ptr(W), K, K, _lib.ptr(da2), _lib.stream()), "dgrad")
+    ref = dy.double() @ W.double()
+    assert rel_err(da.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert torch.equal(da, da2)

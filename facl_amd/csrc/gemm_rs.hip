@@ -81,6 +81,43 @@ __global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, 
     }
 }
 
+// several weight matrices in one launch (the forward and dgrad planes of the three layers of net3DV_3: one ~8 us launch
+// per step instead of six)
+constexpr int RS_MAXJOBS = 8;
+struct RsPlaneJobs {
+    int n;
+    const float* W[RS_MAXJOBS]; long long so[RS_MAXJOBS]; long long sc[RS_MAXJOBS]; int NO[RS_MAXJOBS]; int NC[RS_MAXJOBS];
+    const float* xc[RS_MAXJOBS]; int ldxc[RS_MAXJOBS]; uint4* out[RS_MAXJOBS]; long long first[RS_MAXJOBS + 1];
+};
+__global__ __launch_bounds__(256) void k_rs_planes_multi(RsPlaneJobs jb) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < jb.first[jb.n]; i += (long long)gridDim.x * 256) {
+        int j = 0;
+#pragma unroll
+        for (int t = 1; t < RS_MAXJOBS; ++t) j += (t < jb.n && i >= jb.first[t]) ? 1 : 0;
+        const long long li = i - jb.first[j];
+        const int NT = jb.NO[j] >> 5, nks = jb.NC[j] >> 4;
+        const int ln = (int)(li & 63);
+        const long long t = li >> 6;
+        const int ot = (int)(t % NT), ks = (int)(t / NT);
+        const int o = 32 * ot + (ln & 31), hh = ln >> 5;
+        float v[8];
+        if (ks < nks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = jb.W[j][(long long)o * jb.so[j] + (long long)(16 * ks + 8 * hh + e) * jb.sc[j]];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (hh == 0 && e < 3) ? jb.xc[j][(long long)o * jb.ldxc[j] + e] : 0.f;
+        }
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
+        uint4* d = jb.out[j] + ((long long)(ks * NT + ot) * 3) * 64 + ln;
+        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 struct RsTile { int x, y; };
 // XCD-aware order (as gemm.hip: xcd_tile): each XCD walks a contiguous range of (row group, column block) tiles,
 // column blocks fastest, so the column blocks that re-read one 256-row panel of A hit the same L2.
@@ -169,24 +206,20 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
             r[2 * t + 1] = *reinterpret_cast<const float4*>(base + (((c + 1) ^ akey) << 4));
         }
     };
-    auto make_planes = [&](int j, const float4& r0, const float4& r1, bf16x8 (&P)[3]) {
-        float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    // planes of k-step j as 12 packed registers pk[4*plane + e] (e = pair of k-slots); `half` = which float4 of the two
+    // (k-slots 0..3 / 4..7): the split runs in two instalments, each inside the shadow of one group of six MFMAs
+    auto planes_half = [&](int j, const float4& r, unsigned (&pk)[12], int half) {
+        float v[4] = {r.x, r.y, r.z, r.w};
         if (PRO) {
-            const float4* ts = reinterpret_cast<const float4*>(tab + 16 * j + 8 * h);
-            const float4* tt = reinterpret_cast<const float4*>(tab + RS_KPRO + 16 * j + 8 * h);
-            const float4 s0 = ts[0], s1 = ts[1], t0 = tt[0], t1 = tt[1];
-            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+            const float4 s4 = *reinterpret_cast<const float4*>(tab + 16 * j + 8 * h + 4 * half);
+            const float4 t4 = *reinterpret_cast<const float4*>(tab + RS_KPRO + 16 * j + 8 * h + 4 * half);
+            v[0] = fmaxf(fmaf(s4.x, v[0], t4.x), 0.f); v[1] = fmaxf(fmaf(s4.y, v[1], t4.y), 0.f);
+            v[2] = fmaxf(fmaf(s4.z, v[2], t4.z), 0.f); v[3] = fmaxf(fmaf(s4.w, v[3], t4.w), 0.f);
         }
-        unsigned hi[4], mi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
-        P[0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
-        P[1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
-        P[2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+        split_pair(v[0], v[1], pk[2 * half], pk[4 + 2 * half], pk[8 + 2 * half]);
+        split_pair(v[2], v[3], pk[2 * half + 1], pk[4 + 2 * half + 1], pk[8 + 2 * half + 1]);
     };
+    auto frag = [&](const unsigned (&pk)[12], int p) { return as_bf16x8(pk[4 * p], pk[4 * p + 1], pk[4 * p + 2], pk[4 * p + 3]); };
 
     f32x16 acc[RS_CT];
 #pragma unroll
@@ -194,11 +227,13 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
     constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
-    // MFMAs of one k-step.  The B fragments are double-buffered by hand and the groups are fenced (sched_barrier) so that
-    // the scheduler cannot hoist all 24 fragment reads of the k-step (96 VGPRs) above the first MFMA: with 128
-    // accumulator registers live that spills.  `mid()` runs between the two halves (the next k-step's plane split).
-    auto mfma_step = [&](int j, const bf16x8 (&P)[3], auto&& mid) {
+    // MFMAs of one k-step.  The B fragments of a column tile are requested one whole group (six MFMAs, 192 cycles) before
+    // their first use; sched_barriers pin that order (left alone, the scheduler sinks each read to just above its consumer
+    // and every group then waits out the LDS latency) and keep it from hoisting all 24 reads of the k-step (96 VGPRs) at
+    // once.  `mid_a()` / `mid_b()` run inside the groups of column tiles 2 and 4 (the next k-step's plane split).
+    auto mfma_step = [&](int j, const unsigned (&pk)[12], auto&& mid_a, auto&& mid_b) {
         const uint4* ws = reinterpret_cast<const uint4*>(wring + (j & 1) * RS_WSLOT) + lane;
+        const bf16x8 P[3] = {frag(pk, 0), frag(pk, 1), frag(pk, 2)};
         bf16x8 b0[3], b1[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[p * 64]);
@@ -206,19 +241,23 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         for (int ct = 0; ct < RS_CT; ct += 2) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) b1[p] = __builtin_bit_cast(bf16x8, ws[((ct + 1) * 3 + p) * 64]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ct == 2) mid_a();
+            if (ct == 4) mid_b();
 #pragma unroll
             for (int t = 0; t < 6; ++t) acc[ct] = MFMA_BF16(P[PA[t]], b0[PB[t]], acc[ct]);     // smallest terms first
             __builtin_amdgcn_sched_barrier(0);
             if (ct + 2 < RS_CT) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[((ct + 2) * 3 + p) * 64]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (ct == 2) mid();
 #pragma unroll
             for (int t = 0; t < 6; ++t) acc[ct + 1] = MFMA_BF16(P[PA[t]], b1[PB[t]], acc[ct + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto nop = []() {};
 
     // ---- pipeline.  Weight ring: k-step j in slot j & 1.  VM operations of a wave, in issue order: prologue A(0), W(0);
     // top of k-step j (behind the barrier): W(j+1) [RS_WPP pieces]; at even j = 2s, once the stage's fragments are in
@@ -227,38 +266,40 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     // also lands A(j/2), needed now.  The workgroup barrier behind the wait makes every wave's pieces of W(j) visible and
     // proves that all waves have left k-step j-1, whose slot the next issue overwrites.
     issueA(0); issueW(0);
-    bf16x8 P0[3], P1[3];
+    unsigned P0[12], P1[12];
     float4 raw[4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_stage(raw);
-    make_planes(0, raw[0], raw[1], P0);
+    planes_half(0, raw[0], P0, 0);
+    planes_half(0, raw[1], P0, 1);
     issueW(1);
     for (int j = 0; j + 2 < nks; j += 2) {
         // -- even k-step j (W(j) and this stage's activations landed at the previous wait): MFMAs on P0, P1 from the
         //    stage's second half; the activation slot is free once `raw` is in registers -> next stage's DMA
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issueA((j >> 1) + 1);
-        mfma_step(j, P0, [&]() { make_planes(j + 1, raw[2], raw[3], P1); });
+        mfma_step(j, P0, [&]() { planes_half(j + 1, raw[2], P1, 0); }, [&]() { planes_half(j + 1, raw[3], P1, 1); });
         // -- odd k-step j+1
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issueW(j + 2);
-        mfma_step(j + 1, P1, []() {});
+        mfma_step(j + 1, P1, nop, nop);
         // -- top of the next stage: W(j+2) and A(j/2+1) have landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issueW(j + 3);
         read_stage(raw);
-        make_planes(j + 2, raw[0], raw[1], P0);
+        planes_half(j + 2, raw[0], P0, 0);
+        planes_half(j + 2, raw[1], P0, 1);
     }
     {   // last stage (k-steps nks-2, nks-1): nothing more to stream but the centre k-step
         const int j = nks - 2;
-        mfma_step(j, P0, [&]() { make_planes(j + 1, raw[2], raw[3], P1); });
+        mfma_step(j, P0, [&]() { planes_half(j + 1, raw[2], P1, 0); }, [&]() { planes_half(j + 1, raw[3], P1, 1); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issueW(j + 2);
-        mfma_step(j + 1, P1, []() {});
+        mfma_step(j + 1, P1, nop, nop);
     }
     if (g.centers) {                                                   // the centroid-xyz columns: one more k-step
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -270,10 +311,10 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         unsigned hi[2], mi[2], lo[2];
         split_pair(c0, c1, hi[0], mi[0], lo[0]);
         split_pair(c2, 0.f, hi[1], mi[1], lo[1]);
-        bf16x8 Pc[3] = {as_bf16x8(hi[0], hi[1], 0u, 0u), as_bf16x8(mi[0], mi[1], 0u, 0u), as_bf16x8(lo[0], lo[1], 0u, 0u)};
+        const unsigned Pc[12] = {hi[0], hi[1], 0u, 0u, mi[0], mi[1], 0u, 0u, lo[0], lo[1], 0u, 0u};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mfma_step(nks, Pc, []() {});
+        mfma_step(nks, Pc, nop, nop);
     }
 
     // ---- epilogue: lane = column 256 cb + 32 ct + q, register r = row row0 + rowmap(r, h)
@@ -385,6 +426,31 @@ extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int tr
     const long long total = (long long)(NC / 16 + (Wc ? 1 : 0)) * (NO / 32) * 64;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_rs_planes, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes);
+    return facl_launch_status();
+}
+
+// n <= 8 matrices in ONE launch; arrays of the per-matrix arguments of facl_gemm_rs_planes
+extern "C" int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, const int* N, const int* K,
+                                         const int* transposed, const float* const* Wc, const int* ldwc, void* const* planes,
+                                         void* stream) {
+    if (!W || !ldw || !N || !K || !transposed || !Wc || !ldwc || !planes) return FACL_E_NULL;
+    if (n < 1 || n > RS_MAXJOBS) return FACL_E_SHAPE;
+    RsPlaneJobs jb;
+    jb.n = n;
+    jb.first[0] = 0;
+    for (int j = 0; j < RS_MAXJOBS; ++j) {
+        if (j >= n) { jb.W[j] = nullptr; jb.xc[j] = nullptr; jb.out[j] = nullptr; jb.so[j] = jb.sc[j] = 0; jb.NO[j] = jb.NC[j] = 32; jb.ldxc[j] = 0; jb.first[j + 1] = jb.first[j]; continue; }
+        if (!W[j] || !planes[j]) return FACL_E_NULL;
+        if (N[j] < 1 || K[j] < 1 || ldw[j] < K[j]) return FACL_E_SHAPE;
+        const int NO = transposed[j] ? K[j] : N[j], NC = transposed[j] ? N[j] : K[j];
+        if ((NO & 31) || (NC & 15) || (transposed[j] && Wc[j])) return FACL_E_SHAPE;
+        jb.W[j] = W[j]; jb.so[j] = transposed[j] ? 1 : ldw[j]; jb.sc[j] = transposed[j] ? ldw[j] : 1;
+        jb.NO[j] = NO; jb.NC[j] = NC; jb.xc[j] = Wc[j]; jb.ldxc[j] = ldwc[j]; jb.out[j] = (uint4*)planes[j];
+        jb.first[j + 1] = jb.first[j] + (long long)(NC / 16 + (Wc[j] ? 1 : 0)) * (NO / 32) * 64;
+    }
+    const long long total = jb.first[n];
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_rs_planes_multi, dim3(grid), dim3(256), 0, (hipStream_t)stream, jb);
     return facl_launch_status();
 }
 

@@ -487,6 +487,26 @@ def rs_planes(W, transposed, centers_cols=None):
     return planes
 
 
+def rs_planes_multi(jobs):
+    """`jobs`: list of (W view, transposed, centre-column view or None) -> list of plane buffers, ONE launch."""
+    import ctypes
+    lib = _lib.load_library()
+    n = len(jobs)
+    outs = []
+    for W, tr, xc in jobs:
+        N, K = W.shape
+        nb = lib.facl_gemm_rs_planes_bytes(K if tr else N, N if tr else K, 0 if xc is None else 1)
+        outs.append(_lib.empty(nb, dtype=torch.uint8, device=W.device))
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    _lib.check(lib.facl_gemm_rs_planes_multi(
+        n, vp(*[W.data_ptr() for W, _, _ in jobs]), ip(*[W.stride(0) for W, _, _ in jobs]), ip(*[W.shape[0] for W, _, _ in jobs]),
+        ip(*[W.shape[1] for W, _, _ in jobs]), ip(*[1 if tr else 0 for _, tr, _ in jobs]),
+        vp(*[None if xc is None else xc.data_ptr() for _, _, xc in jobs]),
+        ip(*[0 if xc is None else xc.stride(0) for _, _, xc in jobs]), vp(*[o.data_ptr() for o in outs]), _lib.stream()),
+        "facl_gemm_rs_planes_multi")
+    return outs
+
+
 def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws):
     lib = _lib.load_library()
     M, K = a.shape
@@ -504,14 +524,15 @@ def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws):
     return y, sums, ymax, arg
 
 
-def _rs_dgrad(dy, W, prec):
+def _rs_dgrad(dy, W, prec, planes=None):
     """da = dy W on the row-streamed kernel (fp32-grade arithmetic) or, for the opt-in backward precision, the staged one."""
     if prec != "f32":
         return gemm_dgrad(dy, W, prec=prec)
     lib = _lib.load_library()
     M, N = dy.shape
     K = W.shape[1]
-    planes = rs_planes(W, True)
+    if planes is None:
+        planes = rs_planes(W, True)
     da = _lib.empty((M, K), dtype=torch.float32, device=dy.device)
     with _lib.timed("facl_gemm_rs_dgrad %dx%dx%d" % (M, N, K)):
         _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()),
@@ -568,12 +589,19 @@ class _Net3DV3(torch.autograd.Function):
         pooled, centers = pooled.contiguous(), centers.contiguous()
         W1, W2, W3 = W1.contiguous(), W2.contiguous(), W3.contiguous()
         P = pooled.shape[0]
-        y1, sums1, _, _ = _rs_fwd(pooled, rs_planes(W1[:, 3:], False, W1[:, :3]), W1.shape[0], b1, None, centers, training,
-                                  None, ws)
+        # all weight planes of the step in one launch: forward planes now, dgrad planes kept for the backward (the weights
+        # do not change between the two)
+        jobs = [(W1[:, 3:], False, W1[:, :3]), (W2, False, None), (W3, False, None)]
+        want_bwd = training and backward_precision(ctx.prec) == "f32"
+        if want_bwd:
+            jobs += [(W3, True, None), (W2, True, None), (W1[:, 3:], True, None)]
+        pl = rs_planes_multi(jobs)
+        ctx.bwd_planes = pl[3:] if want_bwd else None
+        y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws)
         bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1)
-        y2, sums2, _, _ = _rs_fwd(y1, rs_planes(W2, False), W2.shape[0], b2, bnc1, None, training, None, ws)
+        y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws)
         bnc2, _ = _forward_bn_consts(y2, bns[1], training, reduce_fn, ws, sums2)
-        y3, sums3, ymax, arg = _rs_fwd(y2, rs_planes(W3, False), W3.shape[0], b3, bnc2, None, training, g3.detach(), ws)
+        y3, sums3, ymax, arg = _rs_fwd(y2, pl[2], W3.shape[0], b3, bnc2, None, training, g3.detach(), ws)
         bnc3, _ = _forward_bn_consts(y3, bns[2], training, reduce_fn, ws, sums3)
         M, C = P // S, W3.shape[0]
         xpre = _lib.empty((M, C), dtype=torch.float32, device=pooled.device)
@@ -605,8 +633,9 @@ class _Net3DV3(torch.autograd.Function):
         dy = _lib.empty_like(y3)
         _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
                                              _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), st), "facl_segmax_bwd_apply")
+        bpl = ctx.bwd_planes if ctx.bwd_planes is not None else (None, None, None)
         dW3 = _wgrad_pro(dy, y2, bnc2, bp)
-        da = _rs_dgrad(dy, W3, bp)
+        da = _rs_dgrad(dy, W3, bp, bpl[0])
         # ---- layers 2 and 1: BN backward rows passes, weight gradient with the recomputed activation, dgrad
         grads = []
         for y, bnc, yin, bnc_in, W in ((y2, bnc2, y1, bnc1, W2), (y1, bnc1, None, None, W1)):
@@ -620,14 +649,14 @@ class _Net3DV3(torch.autograd.Function):
                        "facl_rows_bwd_apply")
             if yin is not None:
                 dW = _wgrad_pro(dy, yin, bnc_in, bp)
-                da = _rs_dgrad(dy, W, bp)
+                da = _rs_dgrad(dy, W, bp, bpl[1])
             else:                                                       # first layer: input = pooled | centres
                 dWh = gemm_wgrad(dy, pooled, prec=bp)
                 dWc = _lib.empty((C, 3), **f64)
                 _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(centers), P, C, _lib.ptr(dWc), _lib.ptr(ws), st),
                            "facl_rows_center_wgrad")
                 dW = torch.cat((dWc.float(), dWh), dim=1)
-                da = _rs_dgrad(dy, W[:, 3:], bp) if ctx.needs_input_grad[0] else None
+                da = _rs_dgrad(dy, W[:, 3:], bp, bpl[2]) if ctx.needs_input_grad[0] else None
             grads.append((dW, dga, dbe))
         (dW2, dga2, dbe2), (dW1, dga1, dbe1) = grads
         # d(bias) of a conv in front of a train-mode BN is identically zero: None leaves the parameter untouched

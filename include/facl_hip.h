@@ -254,6 +254,10 @@ int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, in
 int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
 int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, void* planes,
                         void* stream);
+/* n <= 8 matrices in one launch: arrays (length n) of the per-matrix arguments of facl_gemm_rs_planes */
+int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, const int* N, const int* K,
+                              const int* transposed, const float* const* Wc, const int* ldwc, void* const* planes,
+                              void* stream);
 int facl_gemm_rs_supported(int64_t M, int K, int N);
 int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int N, const float* bias, const float* pscale,
                      const float* pshift, const float* centers, float* y, double* sums, const float* sgn, float* ymax,

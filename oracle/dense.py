@@ -131,3 +131,27 @@ def dense_encoder_forward(sd, points, gost, S1, K1, S2, K2, r1, r2, training=Tru
     x_nor = F.normalize(x, p=2, dim=1)
     code = F.linear(x_nor, sd["mapping.weight"])
     return x, code, x_nor, x_global
+
+
+def time_step(B, gost, N, D, repeats=3, S1=512, K1=64, S2=128, K2=64, r1=0.16, r2=0.25):
+    """Wall time (seconds) of `repeats` CPU passes of the dense configuration on a B-clip sample: forward (3-level
+    encoder, train-mode BN) + global + circle losses + backward through every parameter, fp32.  bench.py's cpu_baseline leg
+    for `--config dense` (the product's defaults: S1 = 512, K1 = 64, S2 = 128, K2 = 64; facl_amd/dense.py)."""
+    import time
+    from . import loss as OL
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.as_tensor(v) for k, v in dense_formula_state_dict(D).items()}
+    params = [v for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for p in params:
+        p.requires_grad_(True)
+    order = np.arange(gost)
+    out = []
+    for _ in range(repeats):
+        pts = (torch.rand(B, gost, N, D, generator=g) - 0.5).permute(1, 0, 2, 3).reshape(gost * B, N, D)
+        t0 = time.time()
+        x, _, _, xg = dense_encoder_forward(sd, pts, gost, S1, K1, S2, K2, r1, r2, training=True)
+        loss = OL.global_contrast(gost, xg, x, B) + OL.circle_contrast(gost, x, B, order)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        out.append(time.time() - t0)
+        del grads
+    return out

@@ -67,6 +67,7 @@ SIGNATURES = {
     "facl_gemm_rs_supported": [c_l, c_i, c_i],
     "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_p],
+    "facl_gemm_rs_dgrad_bnstats": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_segmax_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],

@@ -47,6 +47,10 @@ struct RsArgs {
     float* C; int ldc;
     double* part;                                 // statistics partial rows [gridDim.y][2N], or null
     const float* sgn; float* smax; int* sarg;     // my_max_pool over blocks of 64 rows: (M/64, N), or null
+    // dgrad only: the output IS dL/da of a layer a = relu(bn(y)); with `by` (M,N) = that layer's raw output and `bbnc`
+    // (>= 4 x N: mean | invstd | scale | shift) the partial rows hold the BatchNorm-backward sums of the column instead:
+    // (sum_r d, sum_r d * yhat), d = C[r] where scale*y + shift > 0 else 0, yhat = (y - mean) * invstd
+    const float* by; const float* bbnc;
 };
 
 // ---- weights -> fragment-ordered bf16 planes -------------------------------------------------------------------------
@@ -145,7 +149,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <bool PRO, bool SEG>
+template <bool PRO, bool SEG, bool BST>
 __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
@@ -327,19 +331,36 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         const float sg = SEG ? sgn_of(g.sgn[n]) : 1.f;
         float s = 0.f, sq = 0.f, best = 0.f;
         int bp = 0;
+        float yv[16], bmean = 0.f, binv = 0.f, bsc = 0.f, bsh = 0.f;
+        if (BST) {                                                     // the layer's raw output under this tile, all 16 loads in flight
+            bmean = g.bbnc[n]; binv = g.bbnc[g.N + n]; bsc = g.bbnc[2 * g.N + n]; bsh = g.bbnc[3 * g.N + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + rowmap(r, h);
+                yv[r] = row < g.M ? g.by[(size_t)row * g.N + n] : 0.f;
+            }
+        }
+        float q4[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + rowmap(r, h);
             const float v = acc[ct][r] + bias;
             if (row < g.M) {
                 g.C[(size_t)row * g.ldc + n] = v;
-                s += v; sq = fmaf(v, v, sq);
+                if (BST) {                                             // four short chains, then pairwise: ~6 eps on 32 rows
+                    const float d = fmaf(bsc, yv[r], bsh) > 0.f ? v : 0.f;
+                    q4[r >> 2] += d;
+                    g4[r >> 2] = fmaf(d, (yv[r] - bmean) * binv, g4[r >> 2]);
+                } else {
+                    s += v; sq = fmaf(v, v, sq);
+                }
             }
             if (SEG) {
                 const float sv = sg * v;
                 if (r == 0 || sv > best) { best = sv; bp = rowmap(r, 0); }
             }
         }
+        if (BST) { s = (q4[0] + q4[1]) + (q4[2] + q4[3]); sq = (g4[0] + g4[1]) + (g4[2] + g4[3]); }
         if (g.part) {
             const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
             if (h == 0) { wstat[2 * (32 * ct + q)] = st; wstat[2 * (32 * ct + q) + 1] = sqt; }
@@ -389,9 +410,10 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
 int rs_launch(const RsArgs& g, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        const void* fns[4] = {(const void*)k_gemm_rs<false, false>, (const void*)k_gemm_rs<true, false>,
-                              (const void*)k_gemm_rs<false, true>, (const void*)k_gemm_rs<true, true>};
-        for (int i = 0; i < 4; ++i) {
+        const void* fns[5] = {(const void*)k_gemm_rs<false, false, false>, (const void*)k_gemm_rs<true, false, false>,
+                              (const void*)k_gemm_rs<false, true, false>, (const void*)k_gemm_rs<true, true, false>,
+                              (const void*)k_gemm_rs<false, false, true>};
+        for (int i = 0; i < 5; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
             if (e != hipSuccess) return (int)e;
         }
@@ -399,10 +421,11 @@ int rs_launch(const RsArgs& g, hipStream_t st) {
     }
     dim3 grid(g.N / 256, (g.M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     const dim3 blk(64 * RS_WAVES);
-    if (g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true>), grid, blk, RS_LDS, st, g);
-    else if (g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false>), grid, blk, RS_LDS, st, g);
-    else if (g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true>), grid, blk, RS_LDS, st, g);
-    else hipLaunchKernelGGL((k_gemm_rs<false, false>), grid, blk, RS_LDS, st, g);
+    if (g.by) hipLaunchKernelGGL((k_gemm_rs<false, false, true>), grid, blk, RS_LDS, st, g);
+    else if (g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true, false>), grid, blk, RS_LDS, st, g);
+    else if (g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false, false>), grid, blk, RS_LDS, st, g);
+    else if (g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true, false>), grid, blk, RS_LDS, st, g);
+    else hipLaunchKernelGGL((k_gemm_rs<false, false, false>), grid, blk, RS_LDS, st, g);
     return facl_launch_status();
 }
 
@@ -477,7 +500,7 @@ extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* pl
     if (sums && (size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     RsArgs g{a, K, (int)M, K, (const uint4*)planes, N / 32, N, bias, pscale, pshift, centers, y, N,
-             sums ? (double*)ws : nullptr, sgn, ymax, arg};
+             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr};
     int rc = rs_launch(g, st);
     if (rc || !sums) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
@@ -489,6 +512,25 @@ extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void*
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             nullptr, nullptr, nullptr, nullptr};
+             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return rs_launch(g, (hipStream_t)stream);
+}
+
+// facl_gemm_rs_dgrad + the statistics pass of the BatchNorm backward that consumes da: with y (M,K) = the raw output of
+// the layer whose activation relu(bn(y)) fed this GEMM's forward, and bnc (5,K) its constants, sums (K,2) = per column
+// (sum_r d, sum_r d*yhat), d = da[r] where the ReLU was open, yhat = (y - mean)*invstd -- what facl_rows_bwd_stats(da, y, ...)
+// computes, taken from the accumulator tile before it is stored (da and y are not re-read by a statistics pass).
+extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, const void* planes, int K, float* da,
+                                          const float* y, const float* bnc, double* sums, void* ws, void* stream) {
+    if (!dy || !planes || !da || !y || !bnc || !sums || !ws) return FACL_E_NULL;
+    if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
+    if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
+    const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
+    if ((size_t)prow * K * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
+             (double*)ws, nullptr, nullptr, nullptr, y, bnc};
+    int rc = rs_launch(g, st);
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, prow, 2 * K, sums, st);
 }

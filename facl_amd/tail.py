@@ -524,20 +524,31 @@ def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws):
     return y, sums, ymax, arg
 
 
-def _rs_dgrad(dy, W, prec, planes=None):
-    """da = dy W on the row-streamed kernel (fp32-grade arithmetic) or, for the opt-in backward precision, the staged one."""
+_FUSE_BNSTATS = __import__("os").environ.get("FACL_RS_BNSTATS", "1") != "0"      # A/B switch: 0 = separate facl_rows_bwd_stats pass
+
+
+def _rs_dgrad(dy, W, prec, planes=None, bn_y=None, bn_c=None, ws=None):
+    """da = dy W on the row-streamed kernel (fp32-grade arithmetic) or, for the opt-in backward precision, the staged one.
+    With (bn_y, bn_c) also the BatchNorm-backward column sums of the layer that consumes da: returns (da, sums or None)."""
     if prec != "f32":
-        return gemm_dgrad(dy, W, prec=prec)
+        return gemm_dgrad(dy, W, prec=prec), None
     lib = _lib.load_library()
     M, N = dy.shape
     K = W.shape[1]
     if planes is None:
         planes = rs_planes(W, True)
     da = _lib.empty((M, K), dtype=torch.float32, device=dy.device)
+    sums = None
     with _lib.timed("facl_gemm_rs_dgrad %dx%dx%d" % (M, N, K)):
-        _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()),
-                   "facl_gemm_rs_dgrad")
-    return da
+        if bn_y is not None and _FUSE_BNSTATS:
+            sums = _lib.empty((K, 2), dtype=torch.float64, device=dy.device)
+            _lib.check(lib.facl_gemm_rs_dgrad_bnstats(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.ptr(bn_y),
+                                                      _lib.ptr(bn_c), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
+                       "facl_gemm_rs_dgrad_bnstats")
+        else:
+            _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()),
+                       "facl_gemm_rs_dgrad")
+    return da, sums
 
 
 def _wgrad_pro(dy, y, bnc, prec):
@@ -635,28 +646,30 @@ class _Net3DV3(torch.autograd.Function):
                                              _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), st), "facl_segmax_bwd_apply")
         bpl = ctx.bwd_planes if ctx.bwd_planes is not None else (None, None, None)
         dW3 = _wgrad_pro(dy, y2, bnc2, bp)
-        da = _rs_dgrad(dy, W3, bp, bpl[0])
+        # dgrad + the statistics pass of the next BatchNorm backward in one kernel (the tile is still in registers)
+        da, sums = _rs_dgrad(dy, W3, bp, bpl[0], y2, bnc2, ws)
         # ---- layers 2 and 1: BN backward rows passes, weight gradient with the recomputed activation, dgrad
         grads = []
         for y, bnc, yin, bnc_in, W in ((y2, bnc2, y1, bnc1, W2), (y1, bnc1, None, None, W1)):
             C = y.shape[1]
-            sums = _lib.empty((C, 2), **f64)
-            _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), st),
-                       "facl_rows_bwd_stats")
+            if sums is None:
+                sums = _lib.empty((C, 2), **f64)
+                _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(sums), _lib.ptr(ws), st),
+                           "facl_rows_bwd_stats")
             dbe, dga, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)
             dy = _lib.empty_like(y)
             _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), st),
                        "facl_rows_bwd_apply")
             if yin is not None:
                 dW = _wgrad_pro(dy, yin, bnc_in, bp)
-                da = _rs_dgrad(dy, W, bp, bpl[1])
+                da, sums = _rs_dgrad(dy, W, bp, bpl[1], yin, bnc_in, ws)
             else:                                                       # first layer: input = pooled | centres
                 dWh = gemm_wgrad(dy, pooled, prec=bp)
                 dWc = _lib.empty((C, 3), **f64)
                 _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(centers), P, C, _lib.ptr(dWc), _lib.ptr(ws), st),
                            "facl_rows_center_wgrad")
                 dW = torch.cat((dWc.float(), dWh), dim=1)
-                da = _rs_dgrad(dy, W[:, 3:], bp, bpl[2]) if ctx.needs_input_grad[0] else None
+                da = _rs_dgrad(dy, W[:, 3:], bp, bpl[2])[0] if ctx.needs_input_grad[0] else None
             grads.append((dW, dga, dbe))
         (dW2, dga2, dbe2), (dW1, dga1, dbe1) = grads
         # d(bias) of a conv in front of a train-mode BN is identically zero: None leaves the parameter untouched

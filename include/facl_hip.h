@@ -263,6 +263,10 @@ int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int N
                      const float* pshift, const float* centers, float* y, double* sums, const float* sgn, float* ymax,
                      int32_t* arg, void* ws, void* stream);
 int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int K, float* da, void* stream);
+/* facl_gemm_rs_dgrad + facl_rows_bwd_stats(da, y, bnc) in one pass: sums (K,2) = the BatchNorm-backward column sums of the
+ * layer whose activation relu(bn(y)) was this GEMM's forward input, taken from the accumulator tile before it is stored */
+int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, const void* planes, int K, float* da, const float* y,
+                               const float* bnc, double* sums, void* ws, void* stream);
 /* "bf16x3" twins (opt-in precision "x3"; never the default): each operand keeps its two leading bf16 pieces and a
  * multiply-add is three products (hi*mid, mid*hi, hi*hi) instead of six -- relative error of a product <= 3 * 2^-16
  * (results ~1e-5 of an fp64 GEMM; the north_star's tolerance for features / loss is 1e-4), half the MFMA work. */

@@ -258,3 +258,32 @@ def test_gemm_rs_dgrad_equals_gemm_dgrad_and_fp64(M, N, K):
     ref = dy.double() @ W.double()
     assert rel_err(da.cpu().numpy(), ref.cpu().numpy()) < 2e-6
     assert torch.equal(da, da2)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 256), (8100, 1024, 512)])
+def test_gemm_rs_dgrad_bnstats_equals_the_rows_pass(M, N, K):
+    """facl_gemm_rs_dgrad_bnstats: da identical to facl_gemm_rs_dgrad, and the fused BatchNorm-backward column sums equal
+    facl_rows_bwd_stats(da, y, bnc) (fp64 accumulation there, fp32 over 32 rows then fp64 here) and an fp64 evaluation."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / N ** 0.5
+    y = torch.randn(M, K, device=DEV, generator=g)
+    bnc = torch.stack((torch.randn(K, device=DEV, generator=g) * 0.1, torch.rand(K, device=DEV, generator=g) + 0.5,
+                       torch.randn(K, device=DEV, generator=g), torch.randn(K, device=DEV, generator=g) * 0.3,
+                       torch.zeros(K, device=DEV))).contiguous()                      # mean | invstd | scale | shift | (unused)
+    planes = _rs_planes(lib, W, True)
+    p = _lib.ptr
+    da, da2 = _lib.empty(M, K, device=DEV), _lib.empty(M, K, device=DEV)
+    sums, sums2 = _lib.empty(K, 2, dtype=torch.float64, device=DEV), _lib.empty(K, 2, dtype=torch.float64, device=DEV)
+    _lib.check(lib.facl_gemm_rs_dgrad_bnstats(p(dy), M, N, p(planes), K, p(da), p(y), p(bnc), p(sums), p(_ws()), _lib.stream()), "bnstats")
+    _lib.check(lib.facl_gemm_rs_dgrad(p(dy), M, N, p(planes), K, p(da2), _lib.stream()), "dgrad")
+    assert torch.equal(da, da2)
+    _lib.check(lib.facl_rows_bwd_stats(p(da), p(y), M, K, p(bnc), p(sums2), p(_ws()), _lib.stream()), "rows_bwd_stats")
+    d = torch.where(bnc[2] * y + bnc[3] > 0, da, torch.zeros_like(da)).double()
+    yhat = ((y - bnc[0]) * bnc[1]).double()
+    ref = torch.stack((d.sum(0), (d * yhat).sum(0)), 1)
+    scale = torch.stack((d.abs().sum(0), (d * yhat).abs().sum(0)), 1).clamp_min(1e-30)   # sums with cancellation: bound by the magnitudes
+    assert float(((sums - ref).abs() / scale).max()) < 2e-6
+    assert float(((sums - sums2).abs() / scale).max()) < 2e-6

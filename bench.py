@@ -140,6 +140,8 @@ def kernel_models(a, K=64):
     bwd2_f32 = os.environ.get("FACL_BWD2_F32") == "1"
     y2 = 64 * 64 * 4                                   # one (64 pos x 64 ch) fp32 tile
     return {
+        # FPS (when --fps 1): the cloud's xyz read once, m = S picks written; the S-1 passes over the cloud stay on chip
+        "facl_fps": dict(kernel="k_fps", flops=M * S * a.N * 9.0, pipe="valu", bytes=M * (a.N * D * 4.0 + S * 4.0)),
         "facl_group": dict(kernel="k_group", flops=M * S * a.N * 8.0, pipe="valu",
                            bytes=M * (a.N * D * 4.0 + S * K * D * 4.0 + S * 12.0)),
         "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "bf16x6",
@@ -225,7 +227,7 @@ def step_rooflines(a, eager_step, batches, nsteps=8):
         recs.append(r)
     recs.sort(key=lambda r: -r["ms_per_launch"])
     # sub-20-us launches are glue, not roofline material (kept only when nothing else was measured: toy shapes)
-    big = [r for r in recs if r["ms_per_launch"] >= 0.02] or recs
+    big = [r for r in recs if r["ms_per_launch"] >= 0.02 or not r["kernel"].startswith("k_gemm")] or recs
     return big[0], big[1:]
 
 

@@ -22,7 +22,8 @@ def farthest_point_sampling_batch(xyz, sample_num, start_idx):
     fn = {torch.float32: lib.facl_fps_f32, torch.float64: lib.facl_fps_f64}.get(xyz.dtype)
     if fn is None:
         raise TypeError("xyz must be float32 or float64")
-    _lib.check(fn(_lib.ptr(xyz), M, N, ld, sample_num, _lib.ptr(start), _lib.ptr(out), _lib.stream()), "facl_fps")
+    with _lib.timed("facl_fps"):
+        _lib.check(fn(_lib.ptr(xyz), M, N, ld, sample_num, _lib.ptr(start), _lib.ptr(out), _lib.stream()), "facl_fps")
     return out
 
 

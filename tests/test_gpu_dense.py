@@ -119,26 +119,55 @@ def test_dense_step_small_vs_oracle_fp64(precision):
             assert rel_err(st[k].cpu().numpy(), sd64[k].detach().numpy()) < (1e-5 if precision == "f32" else 2e-3), k
 
 
-def test_dense_forward_at_config_size_two_clips():
+_CONFIG_SIZE_ORACLE = {}
+
+
+def _config_size_case():
+    """Inputs + the fp64 oracle forward of the config-size case, evaluated once for both precisions."""
+    if not _CONFIG_SIZE_ORACLE:
+        D, B, G, N = 3, 2, 32, 4096
+        cfg = dict(S1=512, K1=64, S2=128, K2=64, r1=0.16, r2=0.25)
+        torch.manual_seed(3)
+        clip = torch.rand(B, G, N, D) - 0.5
+        order = np.random.RandomState(2).permutation(G)
+        from oracle import dense as OD
+        sd_np = OD.dense_formula_state_dict(D)
+        pts = clip.permute(1, 0, 2, 3).reshape(-1, N, D)
+        with torch.no_grad():
+            from oracle import loss as OL
+            sd = {k: (torch.as_tensor(v).double() if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone()) for k, v in sd_np.items()}
+            x, _, _, xg = OD.dense_encoder_forward(sd, pts.double(), G, cfg["S1"], cfg["K1"], cfg["S2"], cfg["K2"], cfg["r1"], cfg["r2"])
+            l64 = float(OL.global_contrast(G, xg, x, B) + OL.circle_contrast(G, x, B, order))
+        _CONFIG_SIZE_ORACLE.update(D=D, B=B, G=G, N=N, cfg=cfg, clip=clip, order=order, x64=x, xg64=xg, l64=l64)
+    return _CONFIG_SIZE_ORACLE
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_dense_forward_at_config_size_two_clips(precision):
     """N = 4096 points, T = 32 views (the dense configuration's cloud and view counts) for TWO clips (train-mode
     BatchNorm1d needs more than one clip row, in the reference's construction too), default level sizes (S1 = 512,
-    S2 = 128, K = 64), fp32-grade arithmetic: features and loss vs the oracle in fp64."""
+    S2 = 128, K = 64): features and loss vs the oracle in fp64.  "f32": fp32-grade arithmetic, the 1e-4 bar.  "f16": the
+    configuration's own fp16-input MFMA point-MLP (BASELINE configs[4]): operands of the level-1 64->256 layer and of every
+    level-2/3 GEMM rounded to fp16 (2^-11), fp32 accumulation, six such layers with train-mode BatchNorm between them --
+    tolerance WIDENED to 3e-2 on the worst feature row and 1e-2 on the loss (the measured values are printed)."""
     from facl_amd.dense import DenseStep
-    D, B, G, N = 3, 2, 32, 4096
-    cfg = dict(S1=512, K1=64, S2=128, K2=64, r1=0.16, r2=0.25)
-    torch.manual_seed(3)
-    clip = torch.rand(B, G, N, D) - 0.5
-    net, sd_np = _dense_model(D, G, cfg, "f32")
+    c = _config_size_case()
+    D, B, G, N, cfg, clip, order = c["D"], c["B"], c["G"], c["N"], c["cfg"], c["clip"], c["order"]
+    net, sd_np = _dense_model(D, G, cfg, precision)
     taps = {}
     hk = net.register_forward_hook(lambda m, i, o: taps.update(x=o[0].detach().clone(), xg=o[3].detach().clone()))
-    order = np.random.RandomState(2).permutation(G)
     loss, _, _ = DenseStep(net, torch.optim.SGD(net.parameters(), lr=0.0), G)(clip.to(DEV), order=order)
     hk.remove()
-    pts = clip.permute(1, 0, 2, 3).reshape(-1, N, D)
-    x64, xg64, l64, _, _ = _oracle(sd_np, pts, G, cfg, order)
+    x64, xg64, l64 = c["x64"], c["xg64"], c["l64"]
     e_x = max_rel_rows(taps["x"].cpu().numpy(), x64.numpy())
-    print(f"x {e_x:.2e}  loss {loss.item():.6f} vs {l64:.6f}")
-    assert e_x < 1e-4 and abs(loss.item() - l64) < 1e-4 * abs(l64)
-    # x_global of two clips goes through a BatchNorm1d over TWO rows: (a - b)/sqrt((a-b)^2/4 + eps) amplifies fp32 rounding
-    # (same conditioning note as tests/test_oracle_golden.py for the tiny golden): 1e-3 there
-    assert max_rel_rows(taps["xg"].cpu().numpy(), xg64.numpy()) < 1e-3
+    e_xg = max_rel_rows(taps["xg"].cpu().numpy(), xg64.numpy())
+    e_l = abs(loss.item() - l64) / abs(l64)
+    print(f"[{precision}] x {e_x:.2e}  x_global {e_xg:.2e}  loss {loss.item():.6f} vs {l64:.6f} ({e_l:.2e})")
+    if precision == "f32":
+        assert e_x < 1e-4 and e_l < 1e-4
+        # x_global of two clips goes through a BatchNorm1d over TWO rows: (a - b)/sqrt((a-b)^2/4 + eps) amplifies fp32
+        # rounding (same conditioning note as tests/test_oracle_golden.py for the tiny golden): 1e-3 there
+        assert e_xg < 1e-3
+    else:
+        assert e_x < 3e-2 and e_l < 1e-2
+        assert e_xg < 3e-1                                            # the two-row BatchNorm1d amplifies the fp16 rounding likewise

@@ -20,6 +20,7 @@
 // (two waves per cloud, merged through LDS, first row wins ties), 128-B row segments stored straight from registers.
 // Roofline: bf16 MFMA (2.5 PFLOP/s dense; 6 executed FLOPs per algorithmic one).
 #include "common.h"
+#include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
 extern "C" int64_t facl_ws_bytes(void);
@@ -321,9 +322,20 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         mfma_step(nks, Pc, nop, nop);
     }
 
-    // ---- epilogue: lane = column 256 cb + 32 ct + q, register r = row row0 + rowmap(r, h)
-    float* const wstat = reinterpret_cast<float*>(abuf);               // this wave's (sum, sumsq) per column: 2 KiB
-    float* const wbest = wstat + 512;                                  // odd waves: (max, arg) of their 32 rows: 2 KiB
+    // ---- epilogue: lane = column 256 cb + 32 ct + q, register r = row row0 + rowmap(r, h).
+    // The tile leaves through a per-wave 32 x 32 staging image (the wave's activation slot, free now): 16 ds_write_b32 in the
+    // accumulator layout, 4 ds_read_b128 in row-major order, 4 stores of 16 B per lane = whole 128-B lines.  Storing the
+    // accumulator layout directly (16 dword stores per tile, 128 per wave) was store-ISSUE bound: 12 of the 22 us of a
+    // one-wave-of-workgroups launch (ablation).  16-B chunks are XOR-swizzled by (row >> 1) & 7 (the key of the
+    // activation slots): conflict-free for the b32 writes and the b128 reads.  The BatchNorm-backward variant brings
+    // its y tile in the same way, reversed (4 wide loads -> image -> 16 ds_read_b32).
+    // Statistics / max-pool hand-off areas live in the weight-ring slot that the final k-step does NOT read.
+    float* const stg = reinterpret_cast<float*>(abuf);
+    char* const freeslot = wring + (((nks_all - 1) & 1) ^ 1) * RS_WSLOT;
+    float* const wstat = reinterpret_cast<float*>(freeslot + wave * 6144);       // (sum, sumsq) per column: 2 KiB
+    float* const wbest = wstat + 512;                                            // SEG, odd waves: (max, arg): 2 KiB
+    float* const ystg = wstat + 512;                                             // BST: y tile image, 4 KiB
+    const int srow = lane >> 3, schunk = lane & 7;                                // row-major side: 8 lanes per 128-B row
 #pragma unroll
     for (int ct = 0; ct < RS_CT; ++ct) {
         const int n = 256 * cb + 32 * ct + q;
@@ -331,26 +343,36 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         const float sg = SEG ? sgn_of(g.sgn[n]) : 1.f;
         float s = 0.f, sq = 0.f, best = 0.f;
         int bp = 0;
-        float yv[16], bmean = 0.f, binv = 0.f, bsc = 0.f, bsh = 0.f;
-        if (BST) {                                                     // the layer's raw output under this tile, all 16 loads in flight
+        float bmean = 0.f, binv = 0.f, bsc = 0.f, bsh = 0.f;
+        if (BST) {                                                     // the layer's raw output under this tile
             bmean = g.bbnc[n]; binv = g.bbnc[g.N + n]; bsc = g.bbnc[2 * g.N + n]; bsh = g.bbnc[3 * g.N + n];
+            float4 yl[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + rowmap(r, h);
-                yv[r] = row < g.M ? g.by[(size_t)row * g.N + n] : 0.f;
+            for (int t = 0; t < 4; ++t) {
+                const int row = 8 * t + srow;
+                int gr = row0 + row;
+                gr = gr < g.M ? gr : g.M - 1;
+                yl[t] = *reinterpret_cast<const float4*>(g.by + (size_t)gr * g.N + 256 * cb + 32 * ct + 4 * schunk);
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 8 * t + srow;
+                *reinterpret_cast<float4*>(ystg + row * 32 + ((schunk ^ ((row >> 1) & 7)) << 2)) = yl[t];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         float q4[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = row0 + rowmap(r, h);
+            const int p = rowmap(r, h);
             const float v = acc[ct][r] + bias;
-            if (row < g.M) {
-                g.C[(size_t)row * g.ldc + n] = v;
+            stg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)] = v;
+            if (row0 + p < g.M) {
                 if (BST) {                                             // four short chains, then pairwise: ~6 eps on 32 rows
-                    const float d = fmaf(bsc, yv[r], bsh) > 0.f ? v : 0.f;
+                    const float yy = ystg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)];
+                    const float d = fmaf(bsc, yy, bsh) > 0.f ? v : 0.f;
                     q4[r >> 2] += d;
-                    g4[r >> 2] = fmaf(d, (yv[r] - bmean) * binv, g4[r >> 2]);
+                    g4[r >> 2] = fmaf(d, (yy - bmean) * binv, g4[r >> 2]);
                 } else {
                     s += v; sq = fmaf(v, v, sq);
                 }
@@ -360,6 +382,15 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
                 if (r == 0 || sv > best) { best = sv; bp = rowmap(r, 0); }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // same-wave LDS hand-off (lanes swap roles)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 8 * t + srow;
+            const float4 v4 = *reinterpret_cast<const float4*>(stg + row * 32 + ((schunk ^ ((row >> 1) & 7)) << 2));
+            if (row0 + row < g.M)
+                *reinterpret_cast<float4*>(g.C + (size_t)(row0 + row) * g.ldc + 256 * cb + 32 * ct + 4 * schunk) = v4;
+        }
+        asm volatile("" ::: "memory");                                 // the next tile rewrites the image (DS ops stay in order)
         if (BST) { s = (q4[0] + q4[1]) + (q4[2] + q4[3]); sq = (g4[0] + g4[1]) + (g4[2] + g4[3]); }
         if (g.part) {
             const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
@@ -380,7 +411,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     if (!g.part && !SEG) return;
     __syncthreads();
     if (SEG && !(wave & 1) && h == 0) {                                // even wave: rows 0..31 of the cloud; partner: rows 32..63
-        const float* pb = reinterpret_cast<const float*>(lds + RS_LDS_W + (wave + 1) * RS_ASLOT) + 512;
+        const float* pb = reinterpret_cast<const float*>(freeslot + (wave + 1) * 6144) + 512;
         const int cloud = row0 >> 6;
         if (row0 < g.M) {
 #pragma unroll
@@ -399,7 +430,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         double s = 0.0, sq = 0.0;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) {
-            const float* ps = reinterpret_cast<const float*>(lds + RS_LDS_W + w * RS_ASLOT);
+            const float* ps = reinterpret_cast<const float*>(freeslot + w * 6144);
             s += (double)ps[2 * tid]; sq += (double)ps[2 * tid + 1];
         }
         double* pr = g.part + ((size_t)tile.y * g.N + 256 * cb + tid) * 2;

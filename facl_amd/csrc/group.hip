@@ -52,6 +52,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
     const int wave = threadIdx.x >> 6;
     const unsigned long long lt = lanemask_lt();
 
+    uint32_t eguess = 122;                    // wave-persistent exponent guess of the K-th distance^2 (2^-5 .. 2^-4 to start with)
     for (int ci = wave; ci < CENTROIDS_PER_WG; ci += GROUP_THREADS / 64) {
         const int c = blockIdx.x * CENTROIDS_PER_WG + ci;       // wave-uniform
         if (c >= S) break;
@@ -74,11 +75,34 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         uint32_t prefix = 0, hi = 0;
         int below = 0, cand = NPL * 64;                         // padding keys (+inf) are ordinary candidates
         int bit = 30;
-        for (; bit >= 0 && cand != K - below && cand > 64 * CKEYS; --bit) {
-            const uint32_t pivot = prefix | (1u << bit);
+        auto count_below = [&](uint32_t pivot) {                // keys under pivot, over the whole wave
             int c = 0;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) c += __popcll(__ballot(key[j] < pivot));
+            return c;
+        };
+        // Exponent bucket first.  MSB-first, the 8 rounds of bits 30..23 run at full width (NPL compares + ballots each)
+        // and, on clouds of one scale, resolve the SAME exponent for every centroid.  Start from the exponent the wave's
+        // previous centroid found: two counts decide whether the K-th smallest lies in [e*2^23, (e+1)*2^23) -- that IS the
+        // loop invariant below < K <= below + cand at bit 22 -- and a miss moves the bucket one step (one more count).
+        // After a few misses the plain MSB-first loop takes over; exactness never depends on the guess.
+        {
+            uint32_t e = eguess;
+            int cl = e ? count_below(e << 23) : 0, ch = count_below((e + 1) << 23);
+            int tries = 0;
+            for (; tries < 4; ++tries) {
+                if (cl >= K) { ch = cl; --e; cl = e ? count_below(e << 23) : 0; }                 // cl >= K >= 1 implies e > 0
+                else if (ch < K) { cl = ch; ++e; ch = count_below((e + 1) << 23); }               // e + 1 <= 255: K <= N real keys are < +inf
+                else break;
+            }
+            if (cl < K && K <= ch) {
+                prefix = e << 23; hi = 0xFF800000u; below = cl; cand = ch - cl; bit = 22;
+                eguess = e;
+            }
+        }
+        for (; bit >= 0 && cand != K - below && cand > 64 * CKEYS; --bit) {
+            const uint32_t pivot = prefix | (1u << bit);
+            const int c = count_below(pivot);
             if (c < K) { prefix = pivot; cand -= c - below; below = c; }   // the K-th smallest is >= pivot: bit = 1
             else cand = c - below;
             hi = ~((1u << bit) - 1u);                           // `bit` and everything above it are resolved now

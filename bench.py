@@ -168,7 +168,7 @@ def _gemm_model(label):
     tag = parts[2] if len(parts) > 2 else ""
     pipe = "f16" if tag == "f16" else "bf16x3" if tag == "x3" else ("f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6")
     name = {"facl_gemm_fwd": "k_gemm_sb fwd", "facl_gemm_dgrad": "k_gemm_sb dgrad", "facl_gemm_wgrad": "k_gemm_sb wgrad",
-            "facl_gemm_rs_fwd": "k_gemm_rs fwd", "facl_gemm_rs_dgrad": "k_gemm_rs dgrad"}[kind]
+            "facl_gemm_rs_fwd": "k_gemm_rs fwd", "facl_gemm_rs_dgrad": "k_gemm_rs dgrad", "facl_gemm_rs_wgrad": "k_wgrad_rs wgrad"}[kind]
     return dict(kernel="%s %s%s" % (name, dims, " (fp16 inputs)" if pipe == "f16" else " (bf16x3)" if pipe == "bf16x3" else ""),
                 pipe=pipe, flops=2.0 * m * k * n,
                 bytes=4.0 * (m * k + k * n + m * n))

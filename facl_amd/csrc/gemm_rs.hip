@@ -438,6 +438,183 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     }
 }
 
+
+// ---- weight gradient of the widest layer: dW (N,K) = dy^T f(y), contraction over the rows ------------------------------
+// k_gemm_sb's weight gradient stages BOTH operands through LDS with ~4.3 VALU instructions per MFMA (two waves per SIMD:
+// VALU-issue bound, 0.39 of the bf16 peak at 49152 x 1024 x 512).  Here the contraction index is the ROW index, so an
+// operand fragment (lane = channel, 8 consecutive rows) is 8 dword loads of 128-B row segments -- coalesced as they
+// stand.  The dy^T fragments are private to the wave that owns their 64 output rows n: loaded, split and used in
+// registers.  The f(y) fragments (f = the previous layer's BatchNorm + ReLU, per channel = per lane) are shared by the
+// workgroup's 8 waves: each thread loads, activates and splits ONE fragment of a 32-row stage and stores its three
+// planes in fragment order (3 ds_write_b128); consumers read them back with ds_read_b128.  No transposing reads, no DMA.
+// Workgroup = 8 waves = 512 (n) x 128 (k) outputs, wave = 64 x 128 (8 accumulator tiles); ~2.5 VALU and 0.25 ds_read_b128
+// per MFMA.  grid.z slices the rows; slices are summed in order by k_sum_slices (deterministic).  Same six products per
+// multiply-add in the same order, 16 rows per k-step in row order: bit-identical to k_gemm_sb's weight gradient when the
+// slice boundaries agree (they need not; the tests hold both to fp64).
+constexpr int WG_WAVES = 8;
+struct WgArgs {
+    const float* dy; const float* y; int M, N, K;     // dy (M,N), y (M,K) row-major
+    const float* pscale; const float* pshift;         // (K) or null
+    float* slices; int rows_per_slice;                // slices[z][N][K]; rows_per_slice % 32 == 0
+};
+
+template <bool PRO>
+__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
+    __shared__ __attribute__((aligned(16))) uint4 bring[2][2 * 4 * 3 * 64];        // 2 stages x (2 k-steps x 4 k-tiles x 3 planes x 64 lanes): 48 KiB
+    __shared__ __attribute__((aligned(16))) float stg_all[WG_WAVES][32 * 32];       // epilogue staging, 4 KiB per wave
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 512 + wave * 64;
+    const int p0 = blockIdx.z * g.rows_per_slice;
+    const int p1 = p0 + g.rows_per_slice < g.M ? p0 + g.rows_per_slice : g.M;
+    const int nst = (p1 - p0 + 31) >> 5;                                           // stages of 32 rows (the last may be ragged)
+
+    // producer role: this thread's fragment of a stage = (k-step ks_b, k tile kt_b, lane lb): channel kb, rows 16 ks_b + 8 hb + e
+    const int ks_b = tid >> 8, kt_b = (tid >> 6) & 3, lb = tid & 63;
+    const int kb = k0 + 32 * kt_b + (lb & 31), hb = lb >> 5;
+    const float ps = PRO ? g.pscale[kb] : 1.f, pt = PRO ? g.pshift[kb] : 0.f;
+    const float* ysrc = g.y + kb;
+    const float* dsrc = g.dy + n0 + q;
+    auto load_b = [&](int s, float (&r)[8]) {                                      // rows past p1 contribute zeros (via dy = 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int p = p0 + 32 * s + 16 * ks_b + 8 * hb + e;
+            p = p < p1 ? p : p1 - 1;
+            r[e] = ysrc[(size_t)p * g.K];
+        }
+    };
+    auto store_b = [&](int s, const float (&r)[8]) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = PRO ? fmaxf(fmaf(ps, r[e], pt), 0.f) : r[e];
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
+        uint4* d = &bring[s & 1][((ks_b * 4 + kt_b) * 3) * 64 + lb];
+        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    };
+    // consumer role: dy^T fragments of the wave's two n tiles for both k-steps of a stage: [ks][nt][8]
+    auto load_a = [&](int s, float (&r)[2][2][8]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int p = p0 + 32 * s + 16 * ks + 8 * h + e;
+                const bool in = p < p1;
+                const size_t o = (size_t)(in ? p : p1 - 1) * g.N;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float v = dsrc[o + 32 * nt];
+                    r[ks][nt][e] = in ? v : 0.f;
+                }
+            }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+
+    float rb[8], ra[2][2][8];
+    load_b(0, rb);
+    load_a(0, ra);
+    store_b(0, rb);
+    if (nst > 1) load_b(1, rb);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        float ran[2][2][8];
+        if (s + 1 < nst) load_a(s + 1, ran);                                       // next stage's dy^T fragments in flight
+        const uint4* bs = &bring[s & 1][lane];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_pair(ra[ks][nt][2 * e], ra[ks][nt][2 * e + 1], hi[e], mi[e], lo[e]);
+                af[nt][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
+                af[nt][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
+                af[nt][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bf16x8 bf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, bs[((ks * 4 + kt) * 3 + p) * 64]);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc[0][kt] = MFMA_BF16(af[0][PA[t]], bf[PB[t]], acc[0][kt]);
+                    acc[1][kt] = MFMA_BF16(af[1][PA[t]], bf[PB[t]], acc[1][kt]);
+                }
+            }
+        }
+        if (s + 1 < nst) {
+            store_b(s + 1, rb);                                                    // into the buffer stage s-1 used: all waves left it at the last barrier
+            if (s + 2 < nst) load_b(s + 2, rb);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ra[ks][nt][e] = ran[ks][nt][e];
+        }
+        __syncthreads();                                                           // stage s+1 is written, stage s is read by everyone
+    }
+
+    // ---- epilogue: lane = column k0 + 32 kt + q, register r = row n0 + 32 nt + rowmap(r, h); through the per-wave LDS image
+    float* const stg = stg_all[wave];
+    float* const out = g.slices + (size_t)blockIdx.z * g.N * g.K;
+    const int srow = lane >> 3, schunk = lane & 7;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = rowmap(r, h);
+                stg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)] = acc[nt][kt][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 8 * t + srow;
+                const float4 v4 = *reinterpret_cast<const float4*>(stg + row * 32 + ((schunk ^ ((row >> 1) & 7)) << 2));
+                *reinterpret_cast<float4*>(out + (size_t)(n0 + 32 * nt + row) * g.K + k0 + 32 * kt + 4 * schunk) = v4;
+            }
+            asm volatile("" ::: "memory");
+        }
+}
+
+// sum over the row slices, in order (deterministic); four slice loads in flight per thread
+__global__ void k_wg_sum_slices(const float* __restrict__ part, int nz, long long n4, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 s = p4[i];
+        int z = 1;
+        for (; z + 3 < nz; z += 4) {
+            const float4 v0 = p4[(size_t)z * n4 + i], v1 = p4[(size_t)(z + 1) * n4 + i];
+            const float4 v2 = p4[(size_t)(z + 2) * n4 + i], v3 = p4[(size_t)(z + 3) * n4 + i];
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; z < nz; ++z) {
+            const float4 v = p4[(size_t)z * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
 int rs_launch(const RsArgs& g, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -564,4 +741,44 @@ extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, con
     int rc = rs_launch(g, st);
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * K, sums, st);
+}
+
+// dW (N,K) = dy^T (N,M) f(y) (M,K), f = relu(pscale*y + pshift) per column of y when pscale is given (else identity), on
+// the register-streamed weight-gradient kernel.  N % 512 == 0, K % 128 == 0, M >= 4096; `slices` = scratch for
+// facl_gemm_rs_wgrad_slices(M, N, K) * N * K floats.  FACL_E_CONFIG when the shape is better served by facl_gemm_wgrad[_pro]
+// (fewer than 8 output blocks: the slice count, and with it the partial-slab traffic, would explode).
+extern "C" int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K) {
+    if (M < 4096 || N < 512 || (N & 511) || K < 128 || (K & 127)) return 0;
+    const int tiles = (N / 512) * (K / 128);
+    if (tiles < 8) return 0;
+    int nz = 256 / tiles;
+    if (nz < 1) nz = 1;
+    int rps = (int)((M + nz - 1) / nz);
+    rps = (rps + 31) / 32 * 32;
+    return (int)((M + rps - 1) / rps);
+}
+extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale,
+                                  const float* pshift, float* dW, float* slices, void* stream) {
+    if (!dy || !y || !dW || !slices) return FACL_E_NULL;
+    if ((pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
+    if (M > 0x7fffffff) return FACL_E_SHAPE;
+    const int nz = facl_gemm_rs_wgrad_slices(M, N, K);
+    if (nz < 1) return FACL_E_CONFIG;
+    if (((uintptr_t)slices | (uintptr_t)dW) & 15) return FACL_E_ALIGN;
+    const int tiles = (N / 512) * (K / 128);
+    int nz0 = 256 / tiles;
+    if (nz0 < 1) nz0 = 1;
+    int rps = (int)((M + nz0 - 1) / nz0);
+    rps = (rps + 31) / 32 * 32;
+    hipStream_t st = (hipStream_t)stream;
+    WgArgs g{dy, y, (int)M, N, K, pscale, pshift, slices, rps};
+    dim3 grid(K / 128, N / 512, nz);
+    if (pscale) hipLaunchKernelGGL(k_wgrad_rs<true>, grid, dim3(64 * WG_WAVES), 0, st, g);
+    else hipLaunchKernelGGL(k_wgrad_rs<false>, grid, dim3(64 * WG_WAVES), 0, st, g);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    const long long n4 = (long long)N * K / 4;
+    const int rgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_wg_sum_slices, dim3(rgrid), dim3(256), 0, st, slices, nz, n4, dW);
+    return facl_launch_status();
 }

@@ -551,14 +551,24 @@ def _rs_dgrad(dy, W, prec, planes=None, bn_y=None, bn_c=None, ws=None):
     return da, sums
 
 
+_WGRAD_RS = __import__("os").environ.get("FACL_WGRAD_RS", "1") != "0"            # A/B switch
+
+
 def _wgrad_pro(dy, y, bnc, prec):
     """dW = dy^T relu(bn(y)) with the activation recomputed while staged; falls back to a materialised activation."""
     lib = _lib.load_library()
     M, N = dy.shape
     K = y.shape[1]
+    dW = _lib.empty((N, K), dtype=torch.float32, device=dy.device)
+    nzr = lib.facl_gemm_rs_wgrad_slices(M, N, K) if (prec == "f32" and _WGRAD_RS and y.is_contiguous()) else 0
+    if nzr > 0:                                                         # the widest layer: register-streamed kernel
+        slices = _lib.empty(nzr * N * K, dtype=torch.float32, device=dy.device)
+        with _lib.timed("facl_gemm_rs_wgrad %dx%dx%d" % (M, N, K)):
+            _lib.check(lib.facl_gemm_rs_wgrad(_lib.ptr(dy), _lib.ptr(y), M, N, K, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(dW),
+                                              _lib.ptr(slices), _lib.stream()), "facl_gemm_rs_wgrad")
+        return dW
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     nz = max(1, min((M + 255) // 256, 512 // tiles))
-    dW = _lib.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = _lib.empty(nz * N * K, dtype=torch.float32, device=dy.device)
     fn = lib.facl_gemm_wgrad_pro_x3 if prec == "x3" else lib.facl_gemm_wgrad_pro
     with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):

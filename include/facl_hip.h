@@ -251,6 +251,13 @@ int facl_gemm_wgrad_pro(const float* dy, const float* y, int64_t M, int N, int K
                         const float* pshift, float* dW, float* slices, int nz, void* stream);
 int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
                            const float* pshift, float* dW, float* slices, int nz, void* stream);
+/* Weight gradient of the widest layer on the register-streamed kernel (csrc/gemm_rs.hip: k_wgrad_rs): dW (N,K) =
+ * dy^T f(y), f = relu(pscale*y + pshift) when pscale is given (else identity).  facl_gemm_rs_wgrad_slices returns the number
+ * of row slices the call will use (scratch = that many x N x K floats), or 0 when the shape is not served (N % 512, K % 128,
+ * M >= 4096 and at least 8 output blocks): facl_gemm_rs_wgrad then returns FACL_E_CONFIG and callers use facl_gemm_wgrad[_pro]. */
+int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K);
+int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale, const float* pshift,
+                       float* dW, float* slices, void* stream);
 int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
 int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, void* planes,
                         void* stream);

@@ -287,3 +287,30 @@ def test_gemm_rs_dgrad_bnstats_equals_the_rows_pass(M, N, K):
     scale = torch.stack((d.abs().sum(0), (d * yhat).abs().sum(0)), 1).clamp_min(1e-30)   # sums with cancellation: bound by the magnitudes
     assert float(((sums - ref).abs() / scale).max()) < 2e-6
     assert float(((sums - sums2).abs() / scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,pro", [(8192, 1024, 512, True), (6000, 1024, 512, False), (4096 + 40, 2048, 256, True)])
+def test_gemm_rs_wgrad_vs_fp64_and_staged_kernel(M, N, K, pro):
+    """Register-streamed weight gradient (k_wgrad_rs: dy^T fragments loaded in operand shape, activation recomputed and
+    split once per stage by the workgroup, fragment-ordered LDS planes) vs fp64 and vs facl_gemm_wgrad on a materialised
+    activation; ragged row counts (M % 32 != 0) and the slice boundaries included."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    nz = lib.facl_gemm_rs_wgrad_slices(M, N, K)
+    assert nz >= 1
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    y = torch.randn(M, K, device=DEV, generator=g)
+    ps = torch.rand(K, device=DEV, generator=g) + 0.5 if pro else None
+    pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
+    dW, sl = _lib.empty(N, K, device=DEV), _lib.empty(nz * N * K, device=DEV)
+    p = _lib.ptr
+    _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y), M, N, K, p(ps), p(pt), p(dW), p(sl), _lib.stream()), "rs_wgrad")
+    a = torch.relu(y * ps + pt) if pro else y
+    a64 = torch.relu(y.double() * ps.double() + pt.double()) if pro else y.double()
+    ref = dy.double().t() @ a64
+    assert rel_err(dW.cpu().numpy(), ref.cpu().numpy()) < 3e-6
+    dW2, sl2 = _lib.empty(N, K, device=DEV), _lib.empty(8 * N * K, device=DEV)
+    _lib.check(lib.facl_gemm_wgrad(p(dy), p(a), M, N, K, K, p(dW2), p(sl2), 8, _lib.stream()), "wgrad")
+    assert rel_err(dW.cpu().numpy(), dW2.cpu().numpy()) < 2e-6
+    assert lib.facl_gemm_rs_wgrad_slices(49152, 512, 256) == 0          # too few output blocks: left to the staged kernel

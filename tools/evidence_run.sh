@@ -29,7 +29,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_G
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d "$O/pmc_${TAG}_b" -o b -- $P > "$O/pmc_${TAG}_b.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d "$O/pmc_${TAG}_c" -o c -- $P > "$O/pmc_${TAG}_c.log" 2>&1
 cd "$R"
-python tools/prof_summary.py "$O/prof_$TAG" 34 40 > "$O/prof_${TAG}_summary.txt"
+python tools/prof_summary.py "$O/prof_$TAG" 56 44 > "$O/prof_${TAG}_summary.txt"
 python tools/pmc_summary.py "$O/pmc_${TAG}_fetch" "$O/pmc_${TAG}_write" 24 > "$O/pmc_${TAG}_traffic.md"
 python tools/pmc_mfma_summary.py "$O/pmc_${TAG}_a" "$O/pmc_${TAG}_b" "$O/pmc_${TAG}_mfma_util.json" > "$O/pmc_${TAG}_mfma_util.md"
 python tools/pmc_wave_summary.py "$O/pmc_${TAG}_a" "$O/pmc_${TAG}_c" > "$O/pmc_${TAG}_wave_cycles.md"

@@ -9,16 +9,32 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def d_steps(d):
+    """executed steps of a default run: 3 graph warm-up + W + K timed + K fenced + 8 eager (the capture pass executes nothing)"""
+    return d["warmup"] + 2 * d["steps"] + 8
+
+
 def main():
     tag = sys.argv[1]
     go, pr = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
     names = ["bench_line", "bench_appearance", "bench_dense", "bench_2rank_gloo_rehearsal"]
+    if os.path.exists(os.path.join(go, f"{tag}_bench_fps.json")):
+        names.insert(1, "bench_fps")
     optin = [n for n in ("bench_optin_x3b", "bench_optin_x3") if os.path.exists(os.path.join(go, f"{tag}_{n}.json"))]
     names += optin
     for n in names:
         shutil.copy(os.path.join(go, f"{tag}_{n}.json"), os.path.join(pr, f"{tag}_{n}.json"))
     shutil.copy(os.path.join(go, f"prof_{tag}", "r_kernel_stats.csv"), os.path.join(pr, f"{tag}_default_cmd_kernel_stats.csv"))
     L = {n: json.load(open(os.path.join(pr, f"{tag}_{n}.json"))) for n in names}
+    for extra in ("traffic.md", "mfma_util.md", "mfma_util.json", "wave_cycles.md"):          # PMC summaries of the same run
+        src = os.path.join(go, f"pmc_{tag}_{extra}")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(pr, f"{tag}_pmc_{extra}"))
+    fps_row = ""
+    if "bench_fps" in L:
+        fps_row = (f'| `python bench.py --fps 1` (the same step with the FPS reorder of every view inside the timed region: north_star lists FPS, '
+                   f'the reference loop never calls it) | {L["bench_fps"]["ms_per_step"]} | {L["bench_fps"]["value"]} | `{tag}_bench_fps.json` |\n')
+    steps = 3 + d_steps(L["bench_line"])
     d = L["bench_line"]
     summ = open(os.path.join(go, f"prof_{tag}_summary.txt")).read()
     tbl = ("| kernel | ms/launch (in-step HIP events) | bound | achieved | peak | frac | hbm_frac | PMC traffic / algorithmic bytes |\n"
@@ -33,18 +49,18 @@ def main():
     open(os.path.join(pr, f"{tag}_bench_summary.md"), "w").write(f'''# Round {int(tag[1:])}: bench lines and rocprofv3 --kernel-trace --stats of the driver's command `python3 bench.py`
 
 MI355X, B=32 T=24 N=2048 D=3.  One profiled run = 1 graph-capture step + 3 graph warm-up steps + 5 warm-up + 20 timed steps
-(HIP-graph replay) + 8 eager steps for the in-step kernel timing of the roofline section + the cpu_baseline leg (CPU only).
++ 20 fenced steps (HIP-graph replay) + 8 eager steps for the in-step kernel timing of the roofline section + the cpu_baseline leg (CPU only).
 Command (on the GPU box, from /tmp with TMPDIR=/tmp):
 `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_{tag} -o r -- python3 bench.py`
-Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-step figures below divide by 34 steps).
+Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-step figures below divide by {steps} executed steps).
 
 ## bench.py lines of this build, un-profiled, same box (`profiles/{tag}_bench_*.json`)
 
 | command | ms/step | clips/s | file |
 |---|---|---|---|
 | `python bench.py` (BASELINE configs[1], headline) | {d["ms_per_step"]} | {d["value"]} | `{tag}_bench_line.json` (cpu_baseline {d["cpu_baseline"]["value"]} clips/s on {d["cpu_baseline"]["cores"]} cores) |
-| `python bench.py --config appearance --D 4` (configs[2]) | {L["bench_appearance"]["ms_per_step"]} | {L["bench_appearance"]["value"]} | `{tag}_bench_appearance.json` |
-| `python bench.py --config dense` (configs[4]: B=8 T=32 N=4096, 3-level SA, fp16-input MFMA) | {L["bench_dense"]["ms_per_step"]} | {L["bench_dense"]["value"]} | `{tag}_bench_dense.json` |
+{fps_row}| `python bench.py --config appearance --D 4` (configs[2]) | {L["bench_appearance"]["ms_per_step"]} | {L["bench_appearance"]["value"]} | `{tag}_bench_appearance.json` |
+| `python bench.py --config dense` (configs[4]: B=8 T=32 N=4096, 3-level SA, fp16-input MFMA) | {L["bench_dense"]["ms_per_step"]} | {L["bench_dense"]["value"]} | `{tag}_bench_dense.json` (own metric string; cpu_baseline {L["bench_dense"].get("cpu_baseline", {}).get("value", "-")} clips/s) |
 | `FACL_DIST_BACKEND=gloo python bench.py --gpus 2 --B 16` (2 ranks REHEARSED on one GPU with CPU collectives: launcher, sharded step, SyncBN, all-gather; not a scaling number) | {L["bench_2rank_gloo_rehearsal"]["ms_per_step"]} | {L["bench_2rank_gloo_rehearsal"]["value"]} | `{tag}_bench_2rank_gloo_rehearsal.json` |
 {optin_rows}
 ## Roofline section of `{tag}_bench_line.json` (every heavy entry, timed inside the step)
@@ -53,7 +69,8 @@ Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-ste
 `roofline` = the first row (the longest kernel).  bf16x6 kernels are priced with the bf16 FLOPs they execute (6 per
 algorithmic multiply-add) against 2,500 TFLOP/s; fp32-MFMA kernels (`k_sa_bwd1`, `k_sa_bwd_w3`) with algorithmic FLOPs against
 157.3 TFLOP/s; PMC traffic from `profiles/pmc_traffic.json` (offline `--pmc FETCH_SIZE` / `WRITE_SIZE` passes of this build:
-`{tag}_pmc_hbm_traffic_table.md`).
+`{tag}_pmc_traffic.md`); MFMA-pipe utilisation and the waves' cycle breakdown from the same call: `{tag}_pmc_mfma_util.md`,
+`{tag}_pmc_wave_cycles.md`.
 
 ## rocprofv3 kernel stats of the profiled run
 

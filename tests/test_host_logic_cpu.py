@@ -216,13 +216,16 @@ def test_simulated_ranks_reduce_scatter_layout_equals_allreduce_slice_and_single
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r02_bench_line.json (the last bench.py line measured on an MI355X) carries every field of the driver's
+    """profiles/r03_bench_line.json (the last bench.py line measured on an MI355X) carries every field of the driver's
     contract plus the roofline / cpu_baseline objects; `roofline` is the LONGEST measured kernel (round-1 defect: it was
     hard-wired); bench.py itself needs a GPU and is run by the driver."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
+    assert "fps-reorder off" in d["config"]["workload"] and "ms_per_step_median_fenced" in d and d["dtype"] == "f32"
+    dense = json.load(open(os.path.join(root, "profiles", "r03_bench_dense.json")))
+    assert dense["metric"] != d["metric"] and "cpu_baseline" in dense and dense["dtype"] == "f16"
     assert all(d["roofline"]["ms_per_launch"] >= r["ms_per_launch"] for r in d["roofline_more"])
     assert "3 timed steps" in d["cpu_baseline"]["sample"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",

@@ -30,6 +30,41 @@ def main():
         src = os.path.join(go, f"pmc_{tag}_{extra}")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(pr, f"{tag}_pmc_{extra}"))
+    # profiles/pmc_traffic.json + pmc_mfma_util.json: what bench.py attaches to its roofline records (same shape only)
+    tmd = os.path.join(go, f"pmc_{tag}_traffic.md")
+    if os.path.exists(tmd):
+        rows = {}
+        for line in open(tmd):
+            c = [x.strip() for x in line.strip().strip("|").split("|")]
+            if len(c) == 6 and c[0].startswith("`"):
+                rows[c[0].strip("`")] = float(c[5]) * 1e6
+        pick = lambda pre: next((v for k, v in rows.items() if k.startswith(pre)), None)
+        table = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, `bench.py --steps 2 "
+                             "--warmup 1 --no-cpu-baseline --graph 0`), FETCH doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
+                             f"requests at 64 B); see {tag}_pmc_traffic.md.",
+                 "shape": {"B": 32, "T": 24, "N": 2048, "D": 3}, "build": tag,
+                 "k_sa_bwd1": pick("k_sa_bwd1"), "k_sa_bwd2_sb": pick("k_sa_bwd2_sb"), "k_sa_bwd_w3": pick("k_sa_bwd_w3"),
+                 "k_sa_fwd3_sb": pick("k_sa_fwd3_sb"), "k_sa_fwd2_sb": pick("k_sa_fwd2_sb"), "k_group": pick("k_group"),
+                 "k_gemm_rs fwd 49152x512x1024": pick("k_gemm_rs<true, true, false>"),
+                 "k_gemm_rs fwd 49152x256x512": pick("k_gemm_rs<true, false, false>"),
+                 "k_wgrad_rs wgrad 49152x1024x512": pick("k_wgrad_rs")}
+        json.dump({k: v for k, v in table.items() if v is not None}, open(os.path.join(pr, "pmc_traffic.json"), "w"), indent=1)
+    mj = os.path.join(go, f"pmc_{tag}_mfma_util.json")
+    if os.path.exists(mj):
+        mu = json.load(open(mj))
+        pick = lambda pre: next((v for k, v in mu.items() if k.startswith(pre)), None)
+        out = {"_comment": f"MFMA-pipe utilisation per launch from rocprofv3 --pmc passes of the {tag} build (see {tag}_pmc_mfma_util.md)",
+               "shape": {"B": 32, "T": 24, "N": 2048, "D": 3}, "build": tag}
+        for name, pre in (("k_sa_fwd3_sb", "k_sa_fwd3_sb"), ("k_sa_bwd1", "k_sa_bwd1"), ("k_sa_bwd_w3", "k_sa_bwd_w3"),
+                          ("k_sa_bwd2_sb", "k_sa_bwd2_sb"), ("k_sa_fwd2_sb", "k_sa_fwd2_sb"),
+                          ("k_gemm_rs fwd 49152x512x1024", "k_gemm_rs<true, true, false>"),
+                          ("k_gemm_rs fwd 49152x256x512", "k_gemm_rs<true, false, false>"),
+                          ("k_wgrad_rs wgrad 49152x1024x512", "k_wgrad_rs")):
+            v = pick(pre)
+            if v:
+                out[name] = {"busy_frac": round(v["busy_frac"], 4), "MfmaUtil": None if v["MfmaUtil"] is None else round(v["MfmaUtil"], 2),
+                             "clock_ghz": round(v["clock_ghz"], 3)}
+        json.dump(out, open(os.path.join(pr, "pmc_mfma_util.json"), "w"), indent=1)
     fps_row = ""
     if "bench_fps" in L:
         fps_row = (f'| `python bench.py --fps 1` (the same step with the FPS reorder of every view inside the timed region: north_star lists FPS, '

@@ -42,6 +42,7 @@ SIGNATURES = {
     "facl_sa_l1tab": [c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_fwd3_h3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3_f16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_stats": [c_p, c_l, c_i, c_p, c_p, c_p],
@@ -64,10 +65,10 @@ SIGNATURES = {
     "facl_gemm_rs_wgrad_slices": [c_l, c_i, c_i],
     "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_planes_bytes": [c_i, c_i, c_i],
-    "facl_gemm_rs_planes": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
-    "facl_gemm_rs_planes_multi": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_planes": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
+    "facl_gemm_rs_planes_multi": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_supported": [c_l, c_i, c_i],
-    "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_p],
     "facl_gemm_rs_dgrad_bnstats": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],

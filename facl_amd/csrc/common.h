@@ -104,3 +104,37 @@ __device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, 
     const uint4 u = make_uint4(a, b, c, d);
     return __builtin_bit_cast(bf16x8, u);
 }
+
+// ---- "fp16x3": fp32 results from THREE fp16 products ---------------------------------------------------------------------
+// fp16 carries 11 significand bits: x * 2^S = h1 + h2 with h1 = fp16(x 2^S), h2 = fp16(x 2^S - h1) reproduces 22 bits
+// (|x 2^S - h1 - h2| <= 2^-22 |x 2^S|; an h2 that falls into fp16's subnormal range keeps an ABSOLUTE error <= 2^-25, and
+// gfx950's fp16 MFMA takes subnormal inputs at full precision -- checked on the hardware with inputs down to 2^-24), and
+// a*b = h1a*h1b + (h1a*h2b + h2a*h1b) + [h2a*h2b <= 2^-22 |a||b|, dropped].  fp16 x fp16 products are exact in fp32 and
+// v_mfma_f32_32x32x16_f16 accumulates in fp32: a GEMM built this way is 7e-8 from the exact product before accumulation
+// rounding (bf16x6: 6e-9; the fp32 accumulation both share: 2.4e-7), i.e. fp32-GEMM accuracy at HALF the MFMA work, 2/3
+// of the LDS plane traffic and ~2/3 of the split VALU of bf16x6.  What fp16 lacks is range: operands are pre-scaled by
+// exact powers of two (activations 2^4, weights 2^8: |a| < 4094, |w| < 255 before an fp16 overflow turns the result into
+// inf / NaN -- loudly; post-BatchNorm activations and network weights sit orders of magnitude inside) and the accumulator
+// is scaled back by 2^-12 in the epilogue.  Used for the FORWARD contractions; gradients (many orders of magnitude of
+// dynamic range) stay on bf16x6, which has fp32's exponent range.
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// smallest terms first: (lo,hi) (hi,lo) (hi,hi)
+#define FACL_H3_PA {1, 0, 0}
+#define FACL_H3_PB {0, 1, 0}
+#define FACL_H3_SA 16.0f
+#define FACL_H3_SW 256.0f
+#define FACL_H3_UNSCALE (1.0f / 4096.0f)
+// two ALREADY SCALED values -> packed (h1, h2) fp16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2v v = {x0, x1};
+    const f16x2h h = __builtin_convertvector(v, f16x2h);                               // round to nearest even
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2v r = {sub_f32(x0, (float)h[0]), sub_f32(x1, (float)h[1])};            // exact
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2h));
+}
+__device__ __forceinline__ f16x8h as_f16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
+    const uint4 u = make_uint4(a, b, c, d);
+    return __builtin_bit_cast(f16x8h, u);
+}

@@ -52,6 +52,7 @@ struct RsArgs {
     // (>= 4 x N: mean | invstd | scale | shift) the partial rows hold the BatchNorm-backward sums of the column instead:
     // (sum_r d, sum_r d * yhat), d = C[r] where scale*y + shift > 0 else 0, yhat = (y - mean) * invstd
     const float* by; const float* bbnc;
+    int h3;                                       // 1: fp16x3 planes / arithmetic (forward only), 0: bf16x6
 };
 
 // ---- weights -> fragment-ordered bf16 planes -------------------------------------------------------------------------
@@ -59,8 +60,10 @@ struct RsArgs {
 // sc = 1 (y = a W^T); dgrad: so = 1, sc = ldw (da = dy W).  Entry ((ks*NT + o/32)*3 + plane)*64 + 32h + o%32 holds the 8
 // k-slots c = 16ks + 8h + j of column o.  `xc` (forward only): one more k-step whose slots 0..2 (h = 0) are
 // Wc[o][0..2] -- the centroid-xyz columns of torch.cat((yt, xt), 1), cn3d_model_conbag.py:219.
+// `half`: fp16x3 planes (common.h): TWO planes per fragment (h1, h2 of w * 2^8) instead of three bf16 planes; same indexing
+// with 2 in place of 3.
 __global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
-                                                   const float* __restrict__ xc, int ldxc, uint4* __restrict__ out) {
+                                                   const float* __restrict__ xc, int ldxc, uint4* __restrict__ out, int half) {
     const int NT = NO >> 5, nks = NC >> 4;
     const long long total = (long long)(nks + (xc ? 1 : 0)) * NT * 64;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -77,6 +80,14 @@ __global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, 
             for (int j = 0; j < 8; ++j) v[j] = (hh == 0 && j < 3) ? xc[(long long)o * ldxc + j] : 0.f;
         }
         unsigned hi[4], mi[4], lo[4];
+        if (half) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j] * FACL_H3_SW, v[2 * j + 1] * FACL_H3_SW, hi[j], lo[j]);
+            uint4* d = out + ((long long)(ks * NT + ot) * 2) * 64 + ln;
+            d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            d[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
         uint4* d = out + ((long long)(ks * NT + ot) * 3) * 64 + ln;
@@ -93,6 +104,7 @@ struct RsPlaneJobs {
     int n;
     const float* W[RS_MAXJOBS]; long long so[RS_MAXJOBS]; long long sc[RS_MAXJOBS]; int NO[RS_MAXJOBS]; int NC[RS_MAXJOBS];
     const float* xc[RS_MAXJOBS]; int ldxc[RS_MAXJOBS]; uint4* out[RS_MAXJOBS]; long long first[RS_MAXJOBS + 1];
+    int half[RS_MAXJOBS];
 };
 __global__ __launch_bounds__(256) void k_rs_planes_multi(RsPlaneJobs jb) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < jb.first[jb.n]; i += (long long)gridDim.x * 256) {
@@ -114,6 +126,14 @@ __global__ __launch_bounds__(256) void k_rs_planes_multi(RsPlaneJobs jb) {
             for (int e = 0; e < 8; ++e) v[e] = (hh == 0 && e < 3) ? jb.xc[j][(long long)o * jb.ldxc[j] + e] : 0.f;
         }
         unsigned hi[4], mi[4], lo[4];
+        if (jb.half[j]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_pair_h(v[2 * e] * FACL_H3_SW, v[2 * e + 1] * FACL_H3_SW, hi[e], lo[e]);
+            uint4* d = jb.out[j] + ((long long)(ks * NT + ot) * 2) * 64 + ln;
+            d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            d[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
         uint4* d = jb.out[j] + ((long long)(ks * NT + ot) * 3) * 64 + ln;
@@ -150,8 +170,10 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <bool PRO, bool SEG, bool BST>
+template <bool PRO, bool SEG, bool BST, bool H3 = false>
 __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
+    constexpr int NPL = H3 ? 2 : 3;                                     // planes per fragment (fp16x3 / bf16x6, common.h)
+    constexpr int WPP = RS_CT * NPL / RS_WAVES;                         // 1-KiB weight pieces a wave issues per k-step
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,14 +195,14 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
 
     // ---- DMA issue helpers (wave-uniform control flow; VM-counter bookkeeping in the pipeline comment below)
     // this wave's RS_CT / RS_WAVES column tiles are RS_WPP consecutive 1-KiB pieces of a k-step
-    const uint4* wsrc = g.Wp + ((size_t)(RS_CT * cb) * 3 + wave * RS_WPP) * 64 + lane;
-    const size_t wstep = (size_t)g.NT * 3 * 64;                                        // uint4 per k-step
+    const uint4* wsrc = g.Wp + ((size_t)(RS_CT * cb) * NPL + wave * WPP) * 64 + lane;
+    const size_t wstep = (size_t)g.NT * NPL * 64;                                      // uint4 per k-step
     auto issueW = [&](int j) {
         if (j < nks_all) {
-            const unsigned dst = wring_a + (j & 1) * RS_WSLOT + wave * RS_WPP * 1024;
+            const unsigned dst = wring_a + (j & 1) * RS_WSLOT + wave * WPP * 1024;
             const uint4* src = wsrc + (size_t)j * wstep;
 #pragma unroll
-            for (int p = 0; p < RS_WPP; ++p) rs_dma16(src + p * 64, dst + p * 1024);
+            for (int p = 0; p < WPP; ++p) rs_dma16(src + p * 64, dst + p * 1024);
         }
     };
     // activations: piece i = rows 8i + (lane>>3); the 16-B chunk that lands in physical chunk c' of row r is logical
@@ -221,8 +243,13 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
             v[0] = fmaxf(fmaf(s4.x, v[0], t4.x), 0.f); v[1] = fmaxf(fmaf(s4.y, v[1], t4.y), 0.f);
             v[2] = fmaxf(fmaf(s4.z, v[2], t4.z), 0.f); v[3] = fmaxf(fmaf(s4.w, v[3], t4.w), 0.f);
         }
-        split_pair(v[0], v[1], pk[2 * half], pk[4 + 2 * half], pk[8 + 2 * half]);
-        split_pair(v[2], v[3], pk[2 * half + 1], pk[4 + 2 * half + 1], pk[8 + 2 * half + 1]);
+        if (H3) {
+            split_pair_h(v[0] * FACL_H3_SA, v[1] * FACL_H3_SA, pk[2 * half], pk[4 + 2 * half]);
+            split_pair_h(v[2] * FACL_H3_SA, v[3] * FACL_H3_SA, pk[2 * half + 1], pk[4 + 2 * half + 1]);
+        } else {
+            split_pair(v[0], v[1], pk[2 * half], pk[4 + 2 * half], pk[8 + 2 * half]);
+            split_pair(v[2], v[3], pk[2 * half + 1], pk[4 + 2 * half + 1], pk[8 + 2 * half + 1]);
+        }
     };
     auto frag = [&](const unsigned (&pk)[12], int p) { return as_bf16x8(pk[4 * p], pk[4 * p + 1], pk[4 * p + 2], pk[4 * p + 3]); };
 
@@ -236,29 +263,38 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     // their first use; sched_barriers pin that order (left alone, the scheduler sinks each read to just above its consumer
     // and every group then waits out the LDS latency) and keep it from hoisting all 24 reads of the k-step (96 VGPRs) at
     // once.  `mid_a()` / `mid_b()` run inside the groups of column tiles 2 and 4 (the next k-step's plane split).
+    constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
+    auto mfma_group = [&](f32x16& c, const bf16x8 (&P)[3], const bf16x8 (&b)[3]) {
+        if (H3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                c = MFMA_F16(__builtin_bit_cast(f16x8h, P[HA[t]]), __builtin_bit_cast(f16x8h, b[HB[t]]), c);   // smallest terms first
+        } else {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) c = MFMA_BF16(P[PA[t]], b[PB[t]], c);                                    // smallest terms first
+        }
+    };
     auto mfma_step = [&](int j, const unsigned (&pk)[12], auto&& mid_a, auto&& mid_b) {
         const uint4* ws = reinterpret_cast<const uint4*>(wring + (j & 1) * RS_WSLOT) + lane;
-        const bf16x8 P[3] = {frag(pk, 0), frag(pk, 1), frag(pk, 2)};
+        const bf16x8 P[3] = {frag(pk, 0), frag(pk, 1), frag(pk, H3 ? 1 : 2)};
         bf16x8 b0[3], b1[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[p * 64]);
+        for (int p = 0; p < NPL; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[p * 64]);
 #pragma unroll
         for (int ct = 0; ct < RS_CT; ct += 2) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b1[p] = __builtin_bit_cast(bf16x8, ws[((ct + 1) * 3 + p) * 64]);
+            for (int p = 0; p < NPL; ++p) b1[p] = __builtin_bit_cast(bf16x8, ws[((ct + 1) * NPL + p) * 64]);
             __builtin_amdgcn_sched_barrier(0);
             if (ct == 2) mid_a();
             if (ct == 4) mid_b();
-#pragma unroll
-            for (int t = 0; t < 6; ++t) acc[ct] = MFMA_BF16(P[PA[t]], b0[PB[t]], acc[ct]);     // smallest terms first
+            mfma_group(acc[ct], P, b0);
             __builtin_amdgcn_sched_barrier(0);
             if (ct + 2 < RS_CT) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[((ct + 2) * 3 + p) * 64]);
+                for (int p = 0; p < NPL; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[((ct + 2) * NPL + p) * 64]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int t = 0; t < 6; ++t) acc[ct + 1] = MFMA_BF16(P[PA[t]], b1[PB[t]], acc[ct + 1]);
+            mfma_group(acc[ct + 1], P, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -313,9 +349,15 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
             gr = gr < g.M ? gr : g.M - 1;
             c0 = g.centers[(size_t)gr * 3]; c1 = g.centers[(size_t)gr * 3 + 1]; c2 = g.centers[(size_t)gr * 3 + 2];
         }
-        unsigned hi[2], mi[2], lo[2];
-        split_pair(c0, c1, hi[0], mi[0], lo[0]);
-        split_pair(c2, 0.f, hi[1], mi[1], lo[1]);
+        unsigned hi[2], mi[2] = {0u, 0u}, lo[2];
+        if (H3) {
+            split_pair_h(c0 * FACL_H3_SA, c1 * FACL_H3_SA, hi[0], mi[0]);
+            split_pair_h(c2 * FACL_H3_SA, 0.f, hi[1], mi[1]);
+            lo[0] = lo[1] = 0u;
+        } else {
+            split_pair(c0, c1, hi[0], mi[0], lo[0]);
+            split_pair(c2, 0.f, hi[1], mi[1], lo[1]);
+        }
         const unsigned Pc[12] = {hi[0], hi[1], 0u, 0u, mi[0], mi[1], 0u, 0u, lo[0], lo[1], 0u, 0u};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = rowmap(r, h);
-            const float v = acc[ct][r] + bias;
+            const float v = H3 ? fmaf(acc[ct][r], FACL_H3_UNSCALE, bias) : acc[ct][r] + bias;      // exact power-of-two rescale
             stg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)] = v;
             if (row0 + p < g.M) {
                 if (BST) {                                             // four short chains, then pairwise: ~6 eps on 32 rows
@@ -625,10 +667,12 @@ __global__ void k_wg_sum_slices(const float* __restrict__ part, int nz, long lon
 int rs_launch(const RsArgs& g, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        const void* fns[5] = {(const void*)k_gemm_rs<false, false, false>, (const void*)k_gemm_rs<true, false, false>,
+        const void* fns[9] = {(const void*)k_gemm_rs<false, false, false>, (const void*)k_gemm_rs<true, false, false>,
                               (const void*)k_gemm_rs<false, true, false>, (const void*)k_gemm_rs<true, true, false>,
-                              (const void*)k_gemm_rs<false, false, true>};
-        for (int i = 0; i < 5; ++i) {
+                              (const void*)k_gemm_rs<false, false, true>,
+                              (const void*)k_gemm_rs<false, false, false, true>, (const void*)k_gemm_rs<true, false, false, true>,
+                              (const void*)k_gemm_rs<false, true, false, true>, (const void*)k_gemm_rs<true, true, false, true>};
+        for (int i = 0; i < 9; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
             if (e != hipSuccess) return (int)e;
         }
@@ -637,6 +681,10 @@ int rs_launch(const RsArgs& g, hipStream_t st) {
     dim3 grid(g.N / 256, (g.M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     const dim3 blk(64 * RS_WAVES);
     if (g.by) hipLaunchKernelGGL((k_gemm_rs<false, false, true>), grid, blk, RS_LDS, st, g);
+    else if (g.h3 && g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true, false, true>), grid, blk, RS_LDS, st, g);
+    else if (g.h3 && g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false, false, true>), grid, blk, RS_LDS, st, g);
+    else if (g.h3 && g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true, false, true>), grid, blk, RS_LDS, st, g);
+    else if (g.h3) hipLaunchKernelGGL((k_gemm_rs<false, false, false, true>), grid, blk, RS_LDS, st, g);
     else if (g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true, false>), grid, blk, RS_LDS, st, g);
     else if (g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false, false>), grid, blk, RS_LDS, st, g);
     else if (g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true, false>), grid, blk, RS_LDS, st, g);
@@ -648,14 +696,14 @@ int rs_launch(const RsArgs& g, hipStream_t st) {
 
 extern "C" int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers) {
     if (N < 32 || K < 16) return 0;
-    return (int64_t)(K / 16 + (with_centers ? 1 : 0)) * (N / 32) * 3 * 64 * 16;
+    return (int64_t)(K / 16 + (with_centers ? 1 : 0)) * (N / 32) * 3 * 64 * 16;          // sized for the three-plane form
 }
 
 // planes for y = a W^T (transposed = 0: W (N,K) row-major, leading dimension ldw; output columns N, contraction K;
 // Wc (N,3), leading dimension ldwc, adds the centre k-step) or for da = dy W (transposed = 1: output columns K,
 // contraction N).  Output columns must be a multiple of 32, the contraction a multiple of 16.
 extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc,
-                                   void* planes, void* stream) {
+                                   int half, void* planes, void* stream) {
     if (!W || !planes) return FACL_E_NULL;
     if (N < 1 || K < 1 || ldw < K) return FACL_E_SHAPE;
     const int NO = transposed ? K : N, NC = transposed ? N : K;
@@ -663,27 +711,29 @@ extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int tr
     const long long so = transposed ? 1 : ldw, sc = transposed ? ldw : 1;
     const long long total = (long long)(NC / 16 + (Wc ? 1 : 0)) * (NO / 32) * 64;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_rs_planes, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes);
+    hipLaunchKernelGGL(k_rs_planes, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes,
+                       half ? 1 : 0);
     return facl_launch_status();
 }
 
 // n <= 8 matrices in ONE launch; arrays of the per-matrix arguments of facl_gemm_rs_planes
 extern "C" int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, const int* N, const int* K,
-                                         const int* transposed, const float* const* Wc, const int* ldwc, void* const* planes,
-                                         void* stream) {
-    if (!W || !ldw || !N || !K || !transposed || !Wc || !ldwc || !planes) return FACL_E_NULL;
+                                         const int* transposed, const float* const* Wc, const int* ldwc, const int* half,
+                                         void* const* planes, void* stream) {
+    if (!W || !ldw || !N || !K || !transposed || !Wc || !ldwc || !half || !planes) return FACL_E_NULL;
     if (n < 1 || n > RS_MAXJOBS) return FACL_E_SHAPE;
     RsPlaneJobs jb;
     jb.n = n;
     jb.first[0] = 0;
     for (int j = 0; j < RS_MAXJOBS; ++j) {
-        if (j >= n) { jb.W[j] = nullptr; jb.xc[j] = nullptr; jb.out[j] = nullptr; jb.so[j] = jb.sc[j] = 0; jb.NO[j] = jb.NC[j] = 32; jb.ldxc[j] = 0; jb.first[j + 1] = jb.first[j]; continue; }
+        if (j >= n) { jb.W[j] = nullptr; jb.xc[j] = nullptr; jb.out[j] = nullptr; jb.so[j] = jb.sc[j] = 0; jb.NO[j] = jb.NC[j] = 32; jb.ldxc[j] = 0; jb.half[j] = 0; jb.first[j + 1] = jb.first[j]; continue; }
         if (!W[j] || !planes[j]) return FACL_E_NULL;
         if (N[j] < 1 || K[j] < 1 || ldw[j] < K[j]) return FACL_E_SHAPE;
         const int NO = transposed[j] ? K[j] : N[j], NC = transposed[j] ? N[j] : K[j];
         if ((NO & 31) || (NC & 15) || (transposed[j] && Wc[j])) return FACL_E_SHAPE;
         jb.W[j] = W[j]; jb.so[j] = transposed[j] ? 1 : ldw[j]; jb.sc[j] = transposed[j] ? ldw[j] : 1;
         jb.NO[j] = NO; jb.NC[j] = NC; jb.xc[j] = Wc[j]; jb.ldxc[j] = ldwc[j]; jb.out[j] = (uint4*)planes[j];
+        jb.half[j] = half[j] ? 1 : 0;
         jb.first[j + 1] = jb.first[j] + (long long)(NC / 16 + (Wc[j] ? 1 : 0)) * (NO / 32) * 64;
     }
     const long long total = jb.first[n];
@@ -701,7 +751,7 @@ extern "C" int facl_gemm_rs_supported(int64_t M, int K, int N) {
 // f = relu(pscale*a + pshift) per input channel when pscale is given (the previous layer's BatchNorm + ReLU).
 // sums (N,2): per-column (sum, sumsq) of y (or null).  sgn / ymax / arg (all or none): fused my_max_pool over blocks of 64
 // rows as in facl_gemm_fwd_segmax (M % 64 == 0).
-extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int N, const float* bias,
+extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, int N, const float* bias,
                                 const float* pscale, const float* pshift, const float* centers, float* y, double* sums,
                                 const float* sgn, float* ymax, int32_t* arg, void* ws, void* stream) {
     if (!a || !planes || !y || (sums && !ws)) return FACL_E_NULL;
@@ -715,7 +765,7 @@ extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* pl
     if (sums && (size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     RsArgs g{a, K, (int)M, K, (const uint4*)planes, N / 32, N, bias, pscale, pshift, centers, y, N,
-             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr};
+             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr, half ? 1 : 0};
     int rc = rs_launch(g, st);
     if (rc || !sums) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
@@ -727,7 +777,7 @@ extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void*
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     return rs_launch(g, (hipStream_t)stream);
 }
 
@@ -744,7 +794,7 @@ extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, con
     if ((size_t)prow * K * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             (double*)ws, nullptr, nullptr, nullptr, y, bnc};
+             (double*)ws, nullptr, nullptr, nullptr, y, bnc, 0};
     int rc = rs_launch(g, st);
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * K, sums, st);

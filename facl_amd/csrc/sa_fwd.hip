@@ -500,7 +500,15 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
         const float s = sgn_of(sgn3[c3]);
         unsigned hi[4], mi[4], lo[4];
-        if (NP >= 2) {
+        if (NP == 4) {                                      // fp16x3: two fp16 planes of w * 2^8 (plane slots 0 and 1)
+            const float sw = s * FACL_H3_SW;
+            split_pair_h(w0.x * sw, w0.y * sw, hi[0], mi[0]);
+            split_pair_h(w0.z * sw, w0.w * sw, hi[1], mi[1]);
+            split_pair_h(w1.x * sw, w1.y * sw, hi[2], mi[2]);
+            split_pair_h(w1.z * sw, w1.w * sw, hi[3], mi[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lo[j] = 0u;
+        } else if (NP >= 2) {
             split_pair(w0.x * s, w0.y * s, hi[0], mi[0], lo[0]);
             split_pair(w0.z * s, w0.w * s, hi[1], mi[1], lo[1]);
             split_pair(w1.x * s, w1.y * s, hi[2], mi[2], lo[2]);
@@ -520,7 +528,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
         sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
     }
-    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn_of(sgn3[threadIdx.x]);
+    // fp16x3 accumulates (a 2^4)(w 2^8): the bias enters at that scale and the reductions are scaled back at the end
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn_of(sgn3[threadIdx.x]) * (NP == 4 ? 4096.0f : 1.0f);
     __syncthreads();
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
@@ -547,7 +556,11 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                 for (int t = 0; t < 2; ++t) {
                     const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
                     const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
-                    if (NP >= 2) {
+                    if (NP == 4) {
+                        split_pair_h(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f) * FACL_H3_SA, fmaxf(fmaf(sc.y, y.y, sh.y), 0.f) * FACL_H3_SA, hi[2 * t], mi[2 * t]);
+                        split_pair_h(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f) * FACL_H3_SA, fmaxf(fmaf(sc.w, y.w, sh.w), 0.f) * FACL_H3_SA, hi[2 * t + 1], mi[2 * t + 1]);
+                        lo[2 * t] = lo[2 * t + 1] = 0u;
+                    } else if (NP >= 2) {
                         split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
                         split_pair(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1], lo[2 * t + 1]);
                     } else {
@@ -572,8 +585,15 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
             for (int kk = 0; kk < 4; ++kk) {
                 bf16x8 bfr[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, w3p[((ct3 * 4 + kk) * 3 + p) * 64 + lane]);
-                if (NP == 3) {
+                for (int p = 0; p < (NP == 4 ? 2 : 3); ++p) bfr[p] = __builtin_bit_cast(bf16x8, w3p[((ct3 * 4 + kk) * 3 + p) * 64 + lane]);
+                if (NP == 4) {                                              // fp16x3: (lo,hi) (hi,lo) (hi,hi)
+                    constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        acc0 = MFMA_F16(__builtin_bit_cast(f16x8h, ap[0][kk][HA[t]]), __builtin_bit_cast(f16x8h, bfr[HB[t]]), acc0);
+                        acc1 = MFMA_F16(__builtin_bit_cast(f16x8h, ap[1][kk][HA[t]]), __builtin_bit_cast(f16x8h, bfr[HB[t]]), acc1);
+                    }
+                } else if (NP == 3) {
 #pragma unroll
                     for (int t = 0; t < 6; ++t) {
                         acc0 = MFMA_BF16(ap[0][kk][PA[t]], bfr[PB[t]], acc0);
@@ -606,6 +626,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                 s += v; sq = fmaf(v, v, sq);
                 if (v > best) { best = v; bp = 32 + rowmap(r, 0); }
             }
+            if (NP == 4) { s *= FACL_H3_UNSCALE; sq *= FACL_H3_UNSCALE * FACL_H3_UNSCALE; best *= FACL_H3_UNSCALE; }   // exact: powers of two
             bp += 4 * h;
             const float ob = __shfl_xor(best, 32, 64);
             const int op = __shfl_xor(bp, 32, 64);
@@ -699,9 +720,9 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
     const size_t lds = use_f32 ? (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2)
                                : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 256 * sizeof(double2);
     const void* fn = use_f32 ? (const void*)k_sa_fwd3 : prec == 1 ? (const void*)k_sa_fwd3_sb<1>
-                   : prec == 2 ? (const void*)k_sa_fwd3_sb<2> : (const void*)k_sa_fwd3_sb<3>;
-    static bool attr_done[3] = {false, false, false};
-    if (prec < 0 || prec > 2) return FACL_E_CONFIG;
+                   : prec == 2 ? (const void*)k_sa_fwd3_sb<2> : prec == 3 ? (const void*)k_sa_fwd3_sb<4> : (const void*)k_sa_fwd3_sb<3>;
+    static bool attr_done[4] = {false, false, false, false};
+    if (prec < 0 || prec > 3) return FACL_E_CONFIG;
     if (!attr_done[prec]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -716,6 +737,9 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
                            ymax, arg, part);
     else if (prec == 2)
         hipLaunchKernelGGL((k_sa_fwd3_sb<2>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+                           ymax, arg, part);
+    else if (prec == 3)
+        hipLaunchKernelGGL((k_sa_fwd3_sb<4>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
                            ymax, arg, part);
     else
         hipLaunchKernelGGL((k_sa_fwd3_sb<3>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
@@ -735,6 +759,14 @@ extern "C" int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* s
                                 const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
                                 double* sums3, void* ws, void* stream) {
     return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 1);
+}
+
+// fp16x3 twin (csrc/common.h): a2 * 2^4 and W3' * 2^8 as two fp16 planes each, three products per multiply-add, fp32
+// accumulation -- fp32-GEMM accuracy at half the MFMA work of facl_sa_fwd3; the default forward arithmetic of the model
+extern "C" int facl_sa_fwd3_h3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
+                               const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
+                               void* stream) {
+    return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 3);
 }
 
 // "bf16x3" twin (opt-in precision "x3")

@@ -9,6 +9,7 @@ import torch
 
 from . import _lib
 
+_FWD_H3 = __import__("os").environ.get("FACL_FWD_H3", "1") != "0"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 UNIT = 64
@@ -140,7 +141,9 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     sums3 = _lib.empty((256, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd3"):
         # dense configuration: fp16-input 64->256 layer; "x3": the opt-in three-product variant (tail.precision)
-        fwd3 = {"f32": lib.facl_sa_fwd3, "f16": lib.facl_sa_fwd3_f16, "x3": lib.facl_sa_fwd3_x3, "x3b": lib.facl_sa_fwd3}[precision]
+        # "f32" / "x3b": the fp32-grade forward -- fp16x3 (csrc/common.h; FACL_FWD_H3=0 selects bf16x6 for A/B)
+        f32_fwd3 = lib.facl_sa_fwd3_h3 if _FWD_H3 else lib.facl_sa_fwd3
+        fwd3 = {"f32": f32_fwd3, "f16": lib.facl_sa_fwd3_f16, "x3": lib.facl_sa_fwd3_x3, "x3b": f32_fwd3}[precision]
         _lib.check(fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
                                     _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
                                     _lib.ptr(ws), st), "facl_sa_fwd3")

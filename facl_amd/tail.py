@@ -473,7 +473,7 @@ def linear_bn_relu_segmax(h, affine, bn, training, S, reduce_fn=None):
 
 
 # ---- net3DV_3 as ONE pass structure on the row-streamed GEMMs (csrc/gemm_rs.hip) ----------------------------------------
-def rs_planes(W, transposed, centers_cols=None):
+def rs_planes(W, transposed, centers_cols=None, half=False):
     """Fragment-ordered bf16 planes of a weight matrix view (rows x cols, any leading dimension) for facl_gemm_rs_fwd
     (transposed = False) / facl_gemm_rs_dgrad (True).  `centers_cols`: (N,3) view whose columns join as the centre k-step."""
     lib = _lib.load_library()
@@ -482,32 +482,40 @@ def rs_planes(W, transposed, centers_cols=None):
     planes = _lib.empty(nb, dtype=torch.uint8, device=W.device)
     _lib.check(lib.facl_gemm_rs_planes(W.data_ptr(), W.stride(0), N, K, 1 if transposed else 0,
                                        None if centers_cols is None else centers_cols.data_ptr(),
-                                       0 if centers_cols is None else centers_cols.stride(0), _lib.ptr(planes), _lib.stream()),
-               "facl_gemm_rs_planes")
+                                       0 if centers_cols is None else centers_cols.stride(0), 1 if half else 0,
+                                       _lib.ptr(planes), _lib.stream()), "facl_gemm_rs_planes")
     return planes
 
 
 def rs_planes_multi(jobs):
-    """`jobs`: list of (W view, transposed, centre-column view or None) -> list of plane buffers, ONE launch."""
+    """`jobs`: list of (W view, transposed, centre-column view or None[, half]) -> list of plane buffers, ONE launch.
+    half = True: fp16x3 planes (forward arithmetic of csrc/common.h), else bf16x6 planes."""
+    jobs = [(j + (False,))[:4] for j in jobs]
     import ctypes
     lib = _lib.load_library()
     n = len(jobs)
     outs = []
-    for W, tr, xc in jobs:
+    for W, tr, xc, _h in jobs:
         N, K = W.shape
         nb = lib.facl_gemm_rs_planes_bytes(K if tr else N, N if tr else K, 0 if xc is None else 1)
         outs.append(_lib.empty(nb, dtype=torch.uint8, device=W.device))
     vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
     _lib.check(lib.facl_gemm_rs_planes_multi(
-        n, vp(*[W.data_ptr() for W, _, _ in jobs]), ip(*[W.stride(0) for W, _, _ in jobs]), ip(*[W.shape[0] for W, _, _ in jobs]),
-        ip(*[W.shape[1] for W, _, _ in jobs]), ip(*[1 if tr else 0 for _, tr, _ in jobs]),
-        vp(*[None if xc is None else xc.data_ptr() for _, _, xc in jobs]),
-        ip(*[0 if xc is None else xc.stride(0) for _, _, xc in jobs]), vp(*[o.data_ptr() for o in outs]), _lib.stream()),
+        n, vp(*[j[0].data_ptr() for j in jobs]), ip(*[j[0].stride(0) for j in jobs]), ip(*[j[0].shape[0] for j in jobs]),
+        ip(*[j[0].shape[1] for j in jobs]), ip(*[1 if j[1] else 0 for j in jobs]),
+        vp(*[None if j[2] is None else j[2].data_ptr() for j in jobs]),
+        ip(*[0 if j[2] is None else j[2].stride(0) for j in jobs]), ip(*[1 if j[3] else 0 for j in jobs]),
+        vp(*[o.data_ptr() for o in outs]), _lib.stream()),
         "facl_gemm_rs_planes_multi")
     return outs
 
 
-def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws):
+# Forward arithmetic of the row-streamed GEMMs: fp16x3 (two fp16 planes of pre-scaled operands, three products: the same
+# fp32-GEMM accuracy at half the MFMA work, csrc/common.h) unless FACL_FWD_H3=0 selects bf16x6 (A/B, bit-identity tests)
+FWD_H3 = __import__("os").environ.get("FACL_FWD_H3", "1") != "0"
+
+
+def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws, half=False):
     lib = _lib.load_library()
     M, K = a.shape
     y = _lib.empty((M, N), dtype=torch.float32, device=a.device)
@@ -517,8 +525,8 @@ def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws):
         ymax = _lib.empty((M // 64, N), dtype=torch.float32, device=a.device)
         arg = _lib.empty((M // 64, N), dtype=torch.int32, device=a.device)
     ps, pt = (pro[2], pro[3]) if pro is not None else (None, None)
-    with _lib.timed("facl_gemm_rs_fwd %dx%dx%d" % (M, K, N)):
-        _lib.check(lib.facl_gemm_rs_fwd(_lib.ptr(a), M, K, _lib.ptr(planes), N, _lib.ptr(bias), _lib.ptr(ps), _lib.ptr(pt),
+    with _lib.timed("facl_gemm_rs_fwd %dx%dx%d%s" % (M, K, N, " h3" if half else "")):
+        _lib.check(lib.facl_gemm_rs_fwd(_lib.ptr(a), M, K, _lib.ptr(planes), 1 if half else 0, N, _lib.ptr(bias), _lib.ptr(ps), _lib.ptr(pt),
                                         _lib.ptr(centers), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(seg_sgn), _lib.ptr(ymax),
                                         _lib.ptr(arg), _lib.ptr(ws), _lib.stream()), "facl_gemm_rs_fwd")
     return y, sums, ymax, arg
@@ -612,17 +620,18 @@ class _Net3DV3(torch.autograd.Function):
         P = pooled.shape[0]
         # all weight planes of the step in one launch: forward planes now, dgrad planes kept for the backward (the weights
         # do not change between the two)
-        jobs = [(W1[:, 3:], False, W1[:, :3]), (W2, False, None), (W3, False, None)]
+        h3 = FWD_H3
+        jobs = [(W1[:, 3:], False, W1[:, :3], h3), (W2, False, None, h3), (W3, False, None, h3)]
         want_bwd = training and backward_precision(ctx.prec) == "f32"
         if want_bwd:
             jobs += [(W3, True, None), (W2, True, None), (W1[:, 3:], True, None)]
         pl = rs_planes_multi(jobs)
         ctx.bwd_planes = pl[3:] if want_bwd else None
-        y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws)
+        y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws, h3)
         bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1)
-        y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws)
+        y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws, h3)
         bnc2, _ = _forward_bn_consts(y2, bns[1], training, reduce_fn, ws, sums2)
-        y3, sums3, ymax, arg = _rs_fwd(y2, pl[2], W3.shape[0], b3, bnc2, None, training, g3.detach(), ws)
+        y3, sums3, ymax, arg = _rs_fwd(y2, pl[2], W3.shape[0], b3, bnc2, None, training, g3.detach(), ws, h3)
         bnc3, _ = _forward_bn_consts(y3, bns[2], training, reduce_fn, ws, sums3)
         M, C = P // S, W3.shape[0]
         xpre = _lib.empty((M, C), dtype=torch.float32, device=pooled.device)

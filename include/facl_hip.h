@@ -114,6 +114,11 @@ int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const fl
 int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
                      const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
                      void* stream);
+/* fp16x3 twin of facl_sa_fwd3 (csrc/common.h: a2 * 2^4 and W3 * 2^8 as two fp16 planes each, three products per
+ * multiply-add, fp32 accumulation): fp32-GEMM accuracy at half the MFMA work; same outputs.  The model's default. */
+int facl_sa_fwd3_h3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
+                    const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
+                    void* stream);
 int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
                  float* pooled, void* stream);
 
@@ -242,7 +247,11 @@ int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K
  *   facl_gemm_rs_fwd         y = f(a) W^T + bias [+ centers Wc^T], f = relu(pscale*a + pshift) when pscale is given (the
  *                            previous layer's BatchNorm2d + ReLU, :62-63: the activation is never materialised); sums (N,2)
  *                            as facl_gemm_fwd; sgn / ymax / arg (all or none) as facl_gemm_fwd_segmax (M % 64 == 0)
- *   facl_gemm_rs_dgrad       da (M,K) = dy (M,N) W
+ *   `half` (planes and forward): 0 = three bf16 planes, six products per multiply-add (bf16x6); 1 = two fp16 planes of the
+ *                            operands pre-scaled by 2^8 (weights) / 2^4 (activations), THREE products (fp16x3, csrc/common.h):
+ *                            the same fp32-GEMM accuracy (22-bit operands, fp32 accumulation) at half the MFMA work; forward
+ *                            only (|a| < 4094, |w| < 255), the planes must have been built with the same `half`
+ *   facl_gemm_rs_dgrad       da (M,K) = dy (M,N) W   (bf16x6 planes)
  *   facl_gemm_wgrad_pro      dW (N,K) = dy^T relu(pscale*y + pshift): facl_gemm_wgrad whose `a` operand is recomputed from
  *                            the previous layer's raw output y (M,K) while it is staged (the companion of the forward
  *                            prologue: the activation tensor never exists); `_x3`: the opt-in three-product arithmetic.
@@ -259,14 +268,14 @@ int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K);
 int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale, const float* pshift,
                        float* dW, float* slices, void* stream);
 int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
-int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, void* planes,
-                        void* stream);
+int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, int half,
+                        void* planes, void* stream);
 /* n <= 8 matrices in one launch: arrays (length n) of the per-matrix arguments of facl_gemm_rs_planes */
 int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, const int* N, const int* K,
-                              const int* transposed, const float* const* Wc, const int* ldwc, void* const* planes,
-                              void* stream);
+                              const int* transposed, const float* const* Wc, const int* ldwc, const int* half,
+                              void* const* planes, void* stream);
 int facl_gemm_rs_supported(int64_t M, int K, int N);
-int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int N, const float* bias, const float* pscale,
+int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, int N, const float* bias, const float* pscale,
                      const float* pshift, const float* centers, float* y, double* sums, const float* sgn, float* ymax,
                      int32_t* arg, void* ws, void* stream);
 int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int K, float* da, void* stream);

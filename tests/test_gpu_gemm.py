@@ -179,12 +179,12 @@ def test_gemm_x3_twins_within_their_bound(M, K, N):
     assert rel_err(dW.cpu().numpy(), (dy.double().t() @ a.double()).cpu().numpy()) < 5e-5
 
 
-def _rs_planes(lib, W, transposed, Wc=None):
+def _rs_planes(lib, W, transposed, Wc=None, half=0):
     from facl_amd import _lib
     N, K = W.shape
     nb = lib.facl_gemm_rs_planes_bytes(K if transposed else N, N if transposed else K, 1 if Wc is not None else 0)
     planes = _lib.empty(nb, dtype=torch.uint8, device=DEV)
-    _lib.check(lib.facl_gemm_rs_planes(_lib.ptr(W), W.stride(0), N, K, int(transposed), _lib.ptr(Wc), 3, _lib.ptr(planes),
+    _lib.check(lib.facl_gemm_rs_planes(_lib.ptr(W), W.stride(0), N, K, int(transposed), _lib.ptr(Wc), 3, half, _lib.ptr(planes),
                                        _lib.stream()), "rs_planes")
     return planes
 
@@ -214,7 +214,7 @@ def test_gemm_rs_fwd_equals_gemm_fwd_and_fp64(M, K, N, pro, ctr, seg):
     y, sums = _lib.empty(M, N, device=DEV), _lib.empty(N, 2, dtype=torch.float64, device=DEV)
     ymax = _lib.empty(M // 64, N, device=DEV) if seg else None
     arg = _lib.empty(M // 64, N, dtype=torch.int32, device=DEV) if seg else None
-    _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax), p(arg),
+    _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), 0, N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax), p(arg),
                                     p(_ws()), _lib.stream()), "rs_fwd")
     # reference 1: fp64
     a64 = a.double()
@@ -314,3 +314,52 @@ def test_gemm_rs_wgrad_vs_fp64_and_staged_kernel(M, N, K, pro):
     _lib.check(lib.facl_gemm_wgrad(p(dy), p(a), M, N, K, K, p(dW2), p(sl2), 8, _lib.stream()), "wgrad")
     assert rel_err(dW.cpu().numpy(), dW2.cpu().numpy()) < 2e-6
     assert lib.facl_gemm_rs_wgrad_slices(49152, 512, 256) == 0          # too few output blocks: left to the staged kernel
+
+
+@pytest.mark.parametrize("M,K,N,pro,ctr,seg", [(4096, 256, 256, False, True, False), (4000, 256, 512, True, False, False),
+                                               (6144, 512, 1024, True, False, True)])
+def test_gemm_rs_fwd_fp16x3_is_fp32_grade(M, K, N, pro, ctr, seg):
+    """The forward arithmetic of the row-streamed GEMM: fp16x3 (csrc/common.h: operands pre-scaled by exact powers of two,
+    split into two fp16 planes, three products per multiply-add, fp32 accumulation).  Held to the SAME 2e-6 bound against an
+    fp64 product as the bf16x6 kernels, compared with them and with torch's fp32 matmul on the same inputs (the measured
+    errors are printed), on activation-like inputs that include tiny values (fp16 subnormal second pieces) and exact zeros."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=DEV, generator=g) * 1.5
+    a[:, ::7] *= 1e-3                                                   # a band of tiny activations
+    a[:, 3::11] = 0.0
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    ps = torch.rand(K, device=DEV, generator=g) + 0.5 if pro else None
+    pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
+    cen = torch.rand(M, 3, device=DEV, generator=g) - 0.5 if ctr else None
+    Wc = torch.randn(N, 3, device=DEV, generator=g).contiguous() if ctr else None
+    sgn = torch.randn(N, device=DEV, generator=g) if seg else None
+    p = _lib.ptr
+    outs = {}
+    for half in (1, 0):
+        planes = _rs_planes(lib, W, False, Wc, half)
+        y, sums = _lib.empty(M, N, device=DEV), _lib.empty(N, 2, dtype=torch.float64, device=DEV)
+        ymax = _lib.empty(M // 64, N, device=DEV) if seg else None
+        arg = _lib.empty(M // 64, N, dtype=torch.int32, device=DEV) if seg else None
+        _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), half, N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax),
+                                        p(arg), p(_ws()), _lib.stream()), "rs_fwd")
+        outs[half] = (y, sums, ymax, arg)
+    a64 = a.double()
+    if pro:
+        a64 = torch.relu(a64 * ps.double() + pt.double())
+    ref = a64 @ W.double().t() + b.double()
+    if ctr:
+        ref = ref + cen.double() @ Wc.double().t()
+    a32 = torch.relu(a * ps + pt) if pro else a
+    t32 = a32 @ W.t() + b + (cen @ Wc.t() if ctr else 0.0)
+    e_h3, e_x6, e_t = (rel_err(v.cpu().numpy(), ref.cpu().numpy()) for v in (outs[1][0], outs[0][0], t32))
+    print(f"fp16x3 {e_h3:.2e}   bf16x6 {e_x6:.2e}   torch fp32 {e_t:.2e}")
+    assert e_h3 < 2e-6 and e_h3 < 2.0 * max(e_x6, e_t)
+    y, sums, ymax, arg = outs[1]
+    assert rel_err(sums[:, 1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-5
+    if seg:
+        sy = (y * torch.where(sgn < 0, -1.0, 1.0)).view(M // 64, 64, N)
+        assert torch.equal(ymax, sy.max(dim=1).values)
+        assert torch.equal(arg.long(), (sy == ymax.unsqueeze(1)).float().argmax(dim=1))

@@ -50,8 +50,10 @@ SIGNATURES = {
     "facl_rows_segmax": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_bwd_stats": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_bwd_apply": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_rows_bwd_apply_amax": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_segmax_bwd_stats": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "facl_segmax_bwd_apply": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
+    "facl_segmax_bwd_apply_amax": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_segmax": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
@@ -63,14 +65,14 @@ SIGNATURES = {
     "facl_gemm_wgrad_pro": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_gemm_wgrad_pro_x3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_gemm_rs_wgrad_slices": [c_l, c_i, c_i],
-    "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_planes_bytes": [c_i, c_i, c_i],
     "facl_gemm_rs_planes": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_rs_planes_multi": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_supported": [c_l, c_i, c_i],
     "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_p],
-    "facl_gemm_rs_dgrad_bnstats": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p],
+    "facl_gemm_rs_dgrad_bnstats": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_segmax_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_dgrad_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p],
@@ -129,6 +131,9 @@ def check(rc, what):
     if rc != 0:
         msg = _ERR.get(rc, f"hipError {rc}")
         raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+AMAX_WORDS = 2048          # include/facl_hip.h: FACL_AMAX_WORDS
 
 
 def ptr(t):

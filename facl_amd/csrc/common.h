@@ -126,6 +126,11 @@ typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
 #define FACL_H3_SA 16.0f
 #define FACL_H3_SW 256.0f
 #define FACL_H3_UNSCALE (1.0f / 4096.0f)
+// max|dy| of a gradient tensor is kept as float bits in FACL_AMAX_SLOTS slots FACL_AMAX_STRIDE dwords apart (rows.hip writes,
+// gemm_rs.hip reads); the buffer the C ABI calls `amax` is FACL_AMAX_SLOTS * FACL_AMAX_STRIDE uint32, zeroed by the caller
+#define FACL_AMAX_SLOTS 64
+#define FACL_AMAX_STRIDE 32
+static_assert(FACL_AMAX_SLOTS * FACL_AMAX_STRIDE == FACL_AMAX_WORDS, "amax buffer layout");
 // two ALREADY SCALED values -> packed (h1, h2) fp16 pairs (element 0 in the low half)
 __device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, unsigned& lo) {
     const f32x2v v = {x0, x1};

@@ -52,8 +52,25 @@ struct RsArgs {
     // (>= 4 x N: mean | invstd | scale | shift) the partial rows hold the BatchNorm-backward sums of the column instead:
     // (sum_r d, sum_r d * yhat), d = C[r] where scale*y + shift > 0 else 0, yhat = (y - mean) * invstd
     const float* by; const float* bbnc;
-    int h3;                                       // 1: fp16x3 planes / arithmetic (forward only), 0: bf16x6
+    int h3;                                       // 1: fp16x3 planes / arithmetic, 0: bf16x6
+    const unsigned* amax;                         // h3 only: bits of max|A| (device scalar) -> the power-of-two scale of A is
+                                                  // chosen per launch (gradients); null: the fixed activation scale 2^4
 };
+
+// fp16x3 operand scale from the bits of max|x|: the power of two that puts the maximum in [2^13, 2^14) (fp16 overflows at
+// 2^16); sets `uns` = 1 / (scale * FACL_H3_SW).  max = 0 / denormal: the largest scale whose inverse stays normal.
+__device__ __forceinline__ float h3_dynamic_scale(const unsigned* amax, float& uns, float other_scale_log2) {
+    unsigned b = amax[(threadIdx.x & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE];    // one slot per lane (rows.hip: abs_max_slot)
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
+    const int e = (int)((__builtin_amdgcn_readfirstlane(b) >> 23) & 0xff);
+    int se = 267 - e;                                                   // biased exponent of 2^(13 - (e - 127))
+    se = se > 230 ? 230 : se;
+    const int ue = 254 - se - (int)other_scale_log2;                    // biased exponent of 2^-(se - 127) * 2^-other
+    uns = __uint_as_float((unsigned)ue << 23);
+    return __uint_as_float((unsigned)se << 23);
+}
+
 
 // ---- weights -> fragment-ordered bf16 planes -------------------------------------------------------------------------
 // value(o, c) = W[o*so + c*sc]: o = output channel (lane of the B operand), c = contraction index.  forward: so = ldw,
@@ -187,6 +204,8 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     const int row0 = (tile.y * RS_WAVES + wave) * 32;
     const int nks = g.K >> 4, nst = g.K >> 5;
     const int nks_all = nks + (g.centers ? 1 : 0);
+    float sA = FACL_H3_SA, uns = FACL_H3_UNSCALE;                       // fp16x3: scale of the A operand, 1 / (sA * 2^8)
+    if (H3 && g.amax) sA = h3_dynamic_scale(g.amax, uns, 8.f);
 
     if (PRO) {
         for (int i = tid; i < g.K; i += 64 * RS_WAVES) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
@@ -244,8 +263,8 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
             v[2] = fmaxf(fmaf(s4.z, v[2], t4.z), 0.f); v[3] = fmaxf(fmaf(s4.w, v[3], t4.w), 0.f);
         }
         if (H3) {
-            split_pair_h(v[0] * FACL_H3_SA, v[1] * FACL_H3_SA, pk[2 * half], pk[4 + 2 * half]);
-            split_pair_h(v[2] * FACL_H3_SA, v[3] * FACL_H3_SA, pk[2 * half + 1], pk[4 + 2 * half + 1]);
+            split_pair_h(v[0] * sA, v[1] * sA, pk[2 * half], pk[4 + 2 * half]);
+            split_pair_h(v[2] * sA, v[3] * sA, pk[2 * half + 1], pk[4 + 2 * half + 1]);
         } else {
             split_pair(v[0], v[1], pk[2 * half], pk[4 + 2 * half], pk[8 + 2 * half]);
             split_pair(v[2], v[3], pk[2 * half + 1], pk[4 + 2 * half + 1], pk[8 + 2 * half + 1]);
@@ -351,8 +370,8 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         }
         unsigned hi[2], mi[2] = {0u, 0u}, lo[2];
         if (H3) {
-            split_pair_h(c0 * FACL_H3_SA, c1 * FACL_H3_SA, hi[0], mi[0]);
-            split_pair_h(c2 * FACL_H3_SA, 0.f, hi[1], mi[1]);
+            split_pair_h(c0 * sA, c1 * sA, hi[0], mi[0]);
+            split_pair_h(c2 * sA, 0.f, hi[1], mi[1]);
             lo[0] = lo[1] = 0u;
         } else {
             split_pair(c0, c1, hi[0], mi[0], lo[0]);
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = rowmap(r, h);
-            const float v = H3 ? fmaf(acc[ct][r], FACL_H3_UNSCALE, bias) : acc[ct][r] + bias;      // exact power-of-two rescale
+            const float v = H3 ? fmaf(acc[ct][r], uns, bias) : acc[ct][r] + bias;      // exact power-of-two rescale
             stg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)] = v;
             if (row0 + p < g.M) {
                 if (BST) {                                             // four short chains, then pairwise: ~6 eps on 32 rows
@@ -498,11 +517,15 @@ struct WgArgs {
     const float* dy; const float* y; int M, N, K;     // dy (M,N), y (M,K) row-major
     const float* pscale; const float* pshift;         // (K) or null
     float* slices; int rows_per_slice;                // slices[z][N][K]; rows_per_slice % 32 == 0
+    const unsigned* amax;                             // fp16x3 form: bits of max|dy| (device scalar)
 };
 
-template <bool PRO>
+// H3: fp16x3 arithmetic (common.h): dy scaled by the power of two that puts max|dy| in [2^13, 2^14), f(y) by 2^4, two fp16
+// planes each, three products; the accumulators are rescaled (exactly) before the slices are written.
+template <bool PRO, bool H3>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
-    __shared__ __attribute__((aligned(16))) uint4 bring[2][2 * 4 * 3 * 64];        // 2 stages x (2 k-steps x 4 k-tiles x 3 planes x 64 lanes): 48 KiB
+    constexpr int NPL = H3 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) uint4 bring[2][2 * 4 * NPL * 64];      // 2 stages x (2 k-steps x 4 k-tiles x planes x 64 lanes): 48 / 32 KiB
     __shared__ __attribute__((aligned(16))) float stg_all[WG_WAVES][32 * 32];       // epilogue staging, 4 KiB per wave
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -517,6 +540,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
     const int p0 = bz * g.rows_per_slice;
     const int p1 = p0 + g.rows_per_slice < g.M ? p0 + g.rows_per_slice : g.M;
     const int nst = (p1 - p0 + 31) >> 5;                                           // stages of 32 rows (the last may be ragged)
+    float sD = 1.f, uns = 1.f;
+    if (H3) sD = h3_dynamic_scale(g.amax, uns, 4.f);
 
     // producer role: this thread's fragment of a stage = (k-step ks_b, k tile kt_b, lane lb): channel kb, rows 16 ks_b + 8 hb + e
     const int ks_b = tid >> 8, kt_b = (tid >> 6) & 3, lb = tid & 63;
@@ -537,12 +562,17 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = PRO ? fmaxf(fmaf(ps, r[e], pt), 0.f) : r[e];
         unsigned hi[4], mi[4], lo[4];
+        uint4* d = &bring[s & 1][((ks_b * 4 + kt_b) * NPL) * 64 + lb];
+        if (H3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
-        uint4* d = &bring[s & 1][((ks_b * 4 + kt_b) * 3) * 64 + lb];
+            for (int e = 0; e < 4; ++e) split_pair_h(v[2 * e] * FACL_H3_SA, v[2 * e + 1] * FACL_H3_SA, hi[e], mi[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
+            d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
         d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
-        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     };
     // consumer role: dy^T fragments of the wave's two n tiles for both k-steps of a stage: [ks][nt][8]
     auto load_a = [&](int s, float (&r)[2][2][8]) {
@@ -569,6 +599,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
+    constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
 
     float rb[8], ra[2][2][8];
     load_b(0, rb);
@@ -582,25 +613,38 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
         const uint4* bs = &bring[s & 1][lane];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][3];
+            bf16x8 af[2][NPL];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 unsigned hi[4], mi[4], lo[4];
+                if (H3) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split_pair(ra[ks][nt][2 * e], ra[ks][nt][2 * e + 1], hi[e], mi[e], lo[e]);
+                    for (int e = 0; e < 4; ++e) split_pair_h(ra[ks][nt][2 * e] * sD, ra[ks][nt][2 * e + 1] * sD, hi[e], mi[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split_pair(ra[ks][nt][2 * e], ra[ks][nt][2 * e + 1], hi[e], mi[e], lo[e]);
+                    af[nt][NPL - 1] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+                }
                 af[nt][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
                 af[nt][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
-                af[nt][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
             }
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                bf16x8 bf[3];
+                bf16x8 bf[NPL];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, bs[((ks * 4 + kt) * 3 + p) * 64]);
+                for (int p = 0; p < NPL; ++p) bf[p] = __builtin_bit_cast(bf16x8, bs[((ks * 4 + kt) * NPL + p) * 64]);
+                if (H3) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    acc[0][kt] = MFMA_BF16(af[0][PA[t]], bf[PB[t]], acc[0][kt]);
-                    acc[1][kt] = MFMA_BF16(af[1][PA[t]], bf[PB[t]], acc[1][kt]);
+                    for (int t = 0; t < 3; ++t) {
+                        acc[0][kt] = MFMA_F16(__builtin_bit_cast(f16x8h, af[0][HA[t]]), __builtin_bit_cast(f16x8h, bf[HB[t]]), acc[0][kt]);
+                        acc[1][kt] = MFMA_F16(__builtin_bit_cast(f16x8h, af[1][HA[t]]), __builtin_bit_cast(f16x8h, bf[HB[t]]), acc[1][kt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        acc[0][kt] = MFMA_BF16(af[0][PA[t]], bf[PB[t]], acc[0][kt]);
+                        acc[1][kt] = MFMA_BF16(af[1][PA[t]], bf[PB[t]], acc[1][kt]);
+                    }
                 }
             }
         }
@@ -628,7 +672,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = rowmap(r, h);
-                stg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)] = acc[nt][kt][r];
+                stg[p * 32 + (((q >> 2) ^ ((p >> 1) & 7)) << 2) + (q & 3)] = H3 ? acc[nt][kt][r] * uns : acc[nt][kt][r];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -667,12 +711,12 @@ __global__ void k_wg_sum_slices(const float* __restrict__ part, int nz, long lon
 int rs_launch(const RsArgs& g, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        const void* fns[9] = {(const void*)k_gemm_rs<false, false, false>, (const void*)k_gemm_rs<true, false, false>,
+        const void* fns[10] = {(const void*)k_gemm_rs<false, false, true, true>,(const void*)k_gemm_rs<false, false, false>, (const void*)k_gemm_rs<true, false, false>,
                               (const void*)k_gemm_rs<false, true, false>, (const void*)k_gemm_rs<true, true, false>,
                               (const void*)k_gemm_rs<false, false, true>,
                               (const void*)k_gemm_rs<false, false, false, true>, (const void*)k_gemm_rs<true, false, false, true>,
                               (const void*)k_gemm_rs<false, true, false, true>, (const void*)k_gemm_rs<true, true, false, true>};
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < 10; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
             if (e != hipSuccess) return (int)e;
         }
@@ -680,7 +724,8 @@ int rs_launch(const RsArgs& g, hipStream_t st) {
     }
     dim3 grid(g.N / 256, (g.M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     const dim3 blk(64 * RS_WAVES);
-    if (g.by) hipLaunchKernelGGL((k_gemm_rs<false, false, true>), grid, blk, RS_LDS, st, g);
+    if (g.by && g.h3) hipLaunchKernelGGL((k_gemm_rs<false, false, true, true>), grid, blk, RS_LDS, st, g);
+    else if (g.by) hipLaunchKernelGGL((k_gemm_rs<false, false, true>), grid, blk, RS_LDS, st, g);
     else if (g.h3 && g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true, false, true>), grid, blk, RS_LDS, st, g);
     else if (g.h3 && g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false, false, true>), grid, blk, RS_LDS, st, g);
     else if (g.h3 && g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true, false, true>), grid, blk, RS_LDS, st, g);
@@ -765,19 +810,22 @@ extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* pl
     if (sums && (size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     RsArgs g{a, K, (int)M, K, (const uint4*)planes, N / 32, N, bias, pscale, pshift, centers, y, N,
-             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr, half ? 1 : 0};
+             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr, half ? 1 : 0, nullptr};
     int rc = rs_launch(g, st);
     if (rc || !sums) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
 }
 
-// da (M,K) = dy (M,N) W   with `planes` = facl_gemm_rs_planes(W, ..., transposed 1)
-extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int K, float* da, void* stream) {
-    if (!dy || !planes || !da) return FACL_E_NULL;
+// da (M,K) = dy (M,N) W   with `planes` = facl_gemm_rs_planes(W, ..., transposed 1, half).  half = 1 (fp16x3): `amax` = device
+// scalar holding the bits of max|dy| (facl_rows_bwd_apply_amax / facl_segmax_bwd_apply_amax produce it), from which the
+// kernel takes dy's power-of-two scale.
+extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int half, const uint32_t* amax,
+                                  int K, float* da, void* stream) {
+    if (!dy || !planes || !da || (half && !amax)) return FACL_E_NULL;
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, half ? 1 : 0, amax};
     return rs_launch(g, (hipStream_t)stream);
 }
 
@@ -785,16 +833,17 @@ extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void*
 // the layer whose activation relu(bn(y)) fed this GEMM's forward, and bnc (5,K) its constants, sums (K,2) = per column
 // (sum_r d, sum_r d*yhat), d = da[r] where the ReLU was open, yhat = (y - mean)*invstd -- what facl_rows_bwd_stats(da, y, ...)
 // computes, taken from the accumulator tile before it is stored (da and y are not re-read by a statistics pass).
-extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, const void* planes, int K, float* da,
-                                          const float* y, const float* bnc, double* sums, void* ws, void* stream) {
-    if (!dy || !planes || !da || !y || !bnc || !sums || !ws) return FACL_E_NULL;
+extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, const void* planes, int half,
+                                          const uint32_t* amax, int K, float* da, const float* y, const float* bnc,
+                                          double* sums, void* ws, void* stream) {
+    if (!dy || !planes || !da || !y || !bnc || !sums || !ws || (half && !amax)) return FACL_E_NULL;
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
     const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     if ((size_t)prow * K * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             (double*)ws, nullptr, nullptr, nullptr, y, bnc, 0};
+             (double*)ws, nullptr, nullptr, nullptr, y, bnc, half ? 1 : 0, amax};
     int rc = rs_launch(g, st);
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * K, sums, st);
@@ -814,8 +863,9 @@ extern "C" int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K) {
     rps = (rps + 31) / 32 * 32;
     return (int)((M + rps - 1) / rps);
 }
+// amax (or null): fp16x3 arithmetic with dy's scale taken from the bits of max|dy| it points to (device scalar).
 extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale,
-                                  const float* pshift, float* dW, float* slices, void* stream) {
+                                  const float* pshift, const uint32_t* amax, float* dW, float* slices, void* stream) {
     if (!dy || !y || !dW || !slices) return FACL_E_NULL;
     if ((pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
     if (M > 0x7fffffff) return FACL_E_SHAPE;
@@ -828,10 +878,13 @@ extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, in
     int rps = (int)((M + nz0 - 1) / nz0);
     rps = (rps + 31) / 32 * 32;
     hipStream_t st = (hipStream_t)stream;
-    WgArgs g{dy, y, (int)M, N, K, pscale, pshift, slices, rps};
+    WgArgs g{dy, y, (int)M, N, K, pscale, pshift, slices, rps, amax};
     dim3 grid(K / 128, N / 512, nz);
-    if (pscale) hipLaunchKernelGGL(k_wgrad_rs<true>, grid, dim3(64 * WG_WAVES), 0, st, g);
-    else hipLaunchKernelGGL(k_wgrad_rs<false>, grid, dim3(64 * WG_WAVES), 0, st, g);
+    const dim3 blk(64 * WG_WAVES);
+    if (pscale && amax) hipLaunchKernelGGL((k_wgrad_rs<true, true>), grid, blk, 0, st, g);
+    else if (pscale) hipLaunchKernelGGL((k_wgrad_rs<true, false>), grid, blk, 0, st, g);
+    else if (amax) hipLaunchKernelGGL((k_wgrad_rs<false, true>), grid, blk, 0, st, g);
+    else hipLaunchKernelGGL((k_wgrad_rs<false, false>), grid, blk, 0, st, g);
     int rc = facl_launch_status();
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;

@@ -116,6 +116,27 @@ __global__ __launch_bounds__(256) void k_rows_bwd_stats4(const float* __restrict
     }
 }
 
+// max|.| of the tensor a kernel writes, for the consumers that scale it by a power of two (fp16x3 GEMMs, common.h): the bit
+// pattern of a non-negative float orders like the unsigned integer, NaN above everything (so a NaN gradient stays visible).
+// The maximum lives in FACL_AMAX_SLOTS slots, one 128-byte line each (a workgroup uses slot = its linear id mod the slot
+// count: thousands of atomics on ONE address serialise in the L2 -- measured, the pass doubled in time); the consumer takes
+// the maximum over the slots.  A wave reads its slot when it STARTS and skips the atomic when it cannot raise that value
+// (a stale read only costs a redundant atomic).  Lanes that left early (channel tail) are absent from the exchange.
+__device__ __forceinline__ float abs_max4(float m, const float4& v) {
+    const unsigned a = __float_as_uint(m);
+    unsigned b = __float_as_uint(v.x) & 0x7fffffffu, c = __float_as_uint(v.y) & 0x7fffffffu;
+    unsigned d = __float_as_uint(v.z) & 0x7fffffffu, e = __float_as_uint(v.w) & 0x7fffffffu;
+    b = b > c ? b : c; d = d > e ? d : e; b = b > d ? b : d;
+    return __uint_as_float(a > b ? a : b);
+}
+__device__ __forceinline__ unsigned* abs_max_slot(unsigned* amax) {
+    return amax + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE;
+}
+__device__ __forceinline__ void publish_abs_max(unsigned* slot, unsigned seen, float m) {
+    const unsigned b = __float_as_uint(m);
+    if (b > seen) atomicMax(slot, b);                                   // the compiler folds a wave's lanes into one atomic
+}
+
 // dy = scale * (dz - k1 - yhat*k2),  kk = (2,C): k1 = dbeta/P, k2 = dgamma/P
 __global__ void k_rows_bwd_apply(const float* __restrict__ dout, const float* __restrict__ y, long long n, int C,
                                  const float* __restrict__ bnc, const float* __restrict__ kk,
@@ -133,9 +154,13 @@ __global__ void k_rows_bwd_apply(const float* __restrict__ dout, const float* __
 // the same, 4 channels per lane (C % 4 == 0, 16-byte aligned tensors): one (row, channel-quad) per iteration
 __global__ __launch_bounds__(256) void k_rows_bwd_apply4(const float* __restrict__ dout, const float* __restrict__ y,
                                                          int R, int C4, const float* __restrict__ bnc,
-                                                         const float* __restrict__ kk, float* __restrict__ dy) {
+                                                         const float* __restrict__ kk, float* __restrict__ dy,
+                                                         unsigned* __restrict__ amax) {
     const int c4 = blockIdx.x * 256 + threadIdx.x;
     if (c4 >= C4) return;
+    float mx = 0.f;
+    unsigned* const slot = amax ? abs_max_slot(amax) : nullptr;
+    const unsigned seen = amax ? *slot : 0u;
     const int C = 4 * C4;
     const float4 mean = reinterpret_cast<const float4*>(bnc)[c4], inv = reinterpret_cast<const float4*>(bnc + C)[c4];
     const float4 scale = reinterpret_cast<const float4*>(bnc + 2 * C)[c4], shift = reinterpret_cast<const float4*>(bnc + 3 * C)[c4];
@@ -149,7 +174,9 @@ __global__ __launch_bounds__(256) void k_rows_bwd_apply4(const float* __restrict
         out.z = scale.z * ((fmaf(scale.z, v.z, shift.z) > 0.f ? g.z : 0.f) - k1.z - (v.z - mean.z) * inv.z * k2.z);
         out.w = scale.w * ((fmaf(scale.w, v.w, shift.w) > 0.f ? g.w : 0.f) - k1.w - (v.w - mean.w) * inv.w * k2.w);
         reinterpret_cast<float4*>(dy)[o] = out;
+        mx = abs_max4(mx, out);
     }
+    if (amax) publish_abs_max(slot, seen, mx);
 }
 
 // ---- backward through the max over S (+ BN + ReLU): sparse sums, then the dense dy -----------------
@@ -197,10 +224,14 @@ __global__ __launch_bounds__(256) void k_segmax_bwd_apply(const float* __restric
 __global__ __launch_bounds__(256) void k_segmax_bwd_apply4(const float* __restrict__ dxpre, const float* __restrict__ xpre,
                                                            const float* __restrict__ y, const int* __restrict__ arg,
                                                            int S, int C4, const float* __restrict__ bnc,
-                                                           const float* __restrict__ kk, float* __restrict__ dy) {
+                                                           const float* __restrict__ kk, float* __restrict__ dy,
+                                                           unsigned* __restrict__ amax) {
     const int c4 = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
     if (c4 >= C4) return;
+    float mx = 0.f;
+    unsigned* const slot = amax ? abs_max_slot(amax) : nullptr;
+    const unsigned seen = amax ? *slot : 0u;
     const int C = 4 * C4;
     const float4 mean = reinterpret_cast<const float4*>(bnc)[c4], inv = reinterpret_cast<const float4*>(bnc + C)[c4];
     const float4 scale = reinterpret_cast<const float4*>(bnc + 2 * C)[c4];
@@ -219,7 +250,9 @@ __global__ __launch_bounds__(256) void k_segmax_bwd_apply4(const float* __restri
         out.z = scale.z * ((s == a.z ? d.z : 0.f) - k1.z - (v.z - mean.z) * inv.z * k2.z);
         out.w = scale.w * ((s == a.w ? d.w : 0.f) - k1.w - (v.w - mean.w) * inv.w * k2.w);
         db[(size_t)s * C4] = out;
+        mx = abs_max4(mx, out);
     }
+    if (amax) publish_abs_max(slot, seen, mx);
 }
 
 // dWc[c][j] = sum_r dy[r][c] * centers[r][j]: the 3 centroid-xyz columns of the first per-centroid layer's weight
@@ -410,15 +443,24 @@ extern "C" int facl_rows_bwd_stats(const float* dout, const float* y, int64_t R,
 
 extern "C" int facl_rows_bwd_apply(const float* dout, const float* y, int64_t R, int C, const float* bnc,
                                    const float* kk, float* dy, void* stream) {
+    return facl_rows_bwd_apply_amax(dout, y, R, C, bnc, kk, dy, nullptr, stream);
+}
+
+// facl_rows_bwd_apply that also raises *amax (device scalar, zeroed by the caller) to the bits of max|dy|: the operand scale
+// of the fp16x3 GEMMs that consume dy (facl_gemm_rs_dgrad, facl_gemm_rs_wgrad).  Needs the 4-channel form (C % 4 == 0,
+// 16-byte aligned tensors): FACL_E_ALIGN otherwise when amax is given.
+extern "C" int facl_rows_bwd_apply_amax(const float* dout, const float* y, int64_t R, int C, const float* bnc,
+                                        const float* kk, float* dy, uint32_t* amax, void* stream) {
     if (!dout || !y || !bnc || !kk || !dy) return FACL_E_NULL;
     if (R < 1 || C < 1) return FACL_E_SHAPE;
     if (!(C & 3) && R <= 0x7fffffff && !((((uintptr_t)dout) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)bnc) | ((uintptr_t)kk)) & 15)) {
         const int gx = (C / 4 + 255) / 256;
         int gy = 4096 / gx;
         if (gy > R) gy = (int)R;
-        hipLaunchKernelGGL(k_rows_bwd_apply4, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dout, y, (int)R, C / 4, bnc, kk, dy);
+        hipLaunchKernelGGL(k_rows_bwd_apply4, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dout, y, (int)R, C / 4, bnc, kk, dy, amax);
         return facl_launch_status();
     }
+    if (amax) return FACL_E_ALIGN;
     const long long n = R * (long long)C;
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_rows_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, y, n, C, bnc, kk, dy);
@@ -441,14 +483,22 @@ extern "C" int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, cons
 extern "C" int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                                      int64_t M, int S, int C, const float* bnc, const float* kk, float* dy,
                                      void* stream) {
+    return facl_segmax_bwd_apply_amax(dxpre, xpre, y, arg, M, S, C, bnc, kk, dy, nullptr, stream);
+}
+
+// facl_segmax_bwd_apply that also raises *amax to the bits of max|dy| (see facl_rows_bwd_apply_amax)
+extern "C" int facl_segmax_bwd_apply_amax(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
+                                          int64_t M, int S, int C, const float* bnc, const float* kk, float* dy,
+                                          uint32_t* amax, void* stream) {
     if (!dxpre || !xpre || !y || !arg || !bnc || !kk || !dy) return FACL_E_NULL;
     if (M < 1 || M > 65535 || S < 1 || C < 1) return FACL_E_SHAPE;
     if (!(C & 3) && !((((uintptr_t)dxpre) | ((uintptr_t)xpre) | ((uintptr_t)y) | ((uintptr_t)arg) | ((uintptr_t)dy) |
                        ((uintptr_t)bnc) | ((uintptr_t)kk)) & 15)) {
         hipLaunchKernelGGL(k_segmax_bwd_apply4, dim3((C / 4 + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, dxpre,
-                           xpre, y, arg, S, C / 4, bnc, kk, dy);
+                           xpre, y, arg, S, C / 4, bnc, kk, dy, amax);
         return facl_launch_status();
     }
+    if (amax) return FACL_E_ALIGN;
     hipLaunchKernelGGL(k_segmax_bwd_apply, dim3((C + 255) / 256, (int)M), dim3(256), 0, (hipStream_t)stream, dxpre,
                        xpre, y, arg, S, C, bnc, kk, dy);
     return facl_launch_status();

@@ -513,6 +513,9 @@ def rs_planes_multi(jobs):
 # Forward arithmetic of the row-streamed GEMMs: fp16x3 (two fp16 planes of pre-scaled operands, three products: the same
 # fp32-GEMM accuracy at half the MFMA work, csrc/common.h) unless FACL_FWD_H3=0 selects bf16x6 (A/B, bit-identity tests)
 FWD_H3 = __import__("os").environ.get("FACL_FWD_H3", "1") != "0"
+# Backward arithmetic of the row-streamed dgrad / weight-gradient kernels: fp16x3 with the gradient operand's power-of-two
+# scale taken per launch from max|dy| (a device scalar its producer kernel maintains); FACL_BWD_H3=0: bf16x6
+BWD_H3 = __import__("os").environ.get("FACL_BWD_H3", "1") != "0"
 
 
 def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws, half=False):
@@ -535,35 +538,38 @@ def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws, half=Fals
 _FUSE_BNSTATS = __import__("os").environ.get("FACL_RS_BNSTATS", "1") != "0"      # A/B switch: 0 = separate facl_rows_bwd_stats pass
 
 
-def _rs_dgrad(dy, W, prec, planes=None, bn_y=None, bn_c=None, ws=None):
+def _rs_dgrad(dy, W, prec, planes=None, bn_y=None, bn_c=None, ws=None, amax=None):
     """da = dy W on the row-streamed kernel (fp32-grade arithmetic) or, for the opt-in backward precision, the staged one.
-    With (bn_y, bn_c) also the BatchNorm-backward column sums of the layer that consumes da: returns (da, sums or None)."""
+    With (bn_y, bn_c) also the BatchNorm-backward column sums of the layer that consumes da: returns (da, sums or None).
+    `amax` (the _lib.AMAX_WORDS int32 buffer holding the bits of max|dy|): fp16x3 arithmetic; `planes` must then be fp16x3 planes."""
     if prec != "f32":
         return gemm_dgrad(dy, W, prec=prec), None
     lib = _lib.load_library()
     M, N = dy.shape
     K = W.shape[1]
+    half = 0 if amax is None else 1
     if planes is None:
-        planes = rs_planes(W, True)
+        planes = rs_planes(W, True, half=bool(half))
     da = _lib.empty((M, K), dtype=torch.float32, device=dy.device)
     sums = None
-    with _lib.timed("facl_gemm_rs_dgrad %dx%dx%d" % (M, N, K)):
+    with _lib.timed("facl_gemm_rs_dgrad %dx%dx%d%s" % (M, N, K, " h3" if half else "")):
         if bn_y is not None and _FUSE_BNSTATS:
             sums = _lib.empty((K, 2), dtype=torch.float64, device=dy.device)
-            _lib.check(lib.facl_gemm_rs_dgrad_bnstats(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.ptr(bn_y),
-                                                      _lib.ptr(bn_c), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
+            _lib.check(lib.facl_gemm_rs_dgrad_bnstats(_lib.ptr(dy), M, N, _lib.ptr(planes), half, _lib.ptr(amax), K, _lib.ptr(da),
+                                                      _lib.ptr(bn_y), _lib.ptr(bn_c), _lib.ptr(sums), _lib.ptr(ws), _lib.stream()),
                        "facl_gemm_rs_dgrad_bnstats")
         else:
-            _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()),
-                       "facl_gemm_rs_dgrad")
+            _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), half, _lib.ptr(amax), K, _lib.ptr(da),
+                                              _lib.stream()), "facl_gemm_rs_dgrad")
     return da, sums
 
 
 _WGRAD_RS = __import__("os").environ.get("FACL_WGRAD_RS", "1") != "0"            # A/B switch
 
 
-def _wgrad_pro(dy, y, bnc, prec):
-    """dW = dy^T relu(bn(y)) with the activation recomputed while staged; falls back to a materialised activation."""
+def _wgrad_pro(dy, y, bnc, prec, amax=None):
+    """dW = dy^T relu(bn(y)) with the activation recomputed while staged; falls back to a materialised activation.
+    `amax`: bits of max|dy| (device scalar) -> fp16x3 arithmetic where the register-streamed kernel serves the shape."""
     lib = _lib.load_library()
     M, N = dy.shape
     K = y.shape[1]
@@ -571,9 +577,9 @@ def _wgrad_pro(dy, y, bnc, prec):
     nzr = lib.facl_gemm_rs_wgrad_slices(M, N, K) if (prec == "f32" and _WGRAD_RS and y.is_contiguous()) else 0
     if nzr > 0:                                                         # the widest layer: register-streamed kernel
         slices = _lib.empty(nzr * N * K, dtype=torch.float32, device=dy.device)
-        with _lib.timed("facl_gemm_rs_wgrad %dx%dx%d" % (M, N, K)):
-            _lib.check(lib.facl_gemm_rs_wgrad(_lib.ptr(dy), _lib.ptr(y), M, N, K, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(dW),
-                                              _lib.ptr(slices), _lib.stream()), "facl_gemm_rs_wgrad")
+        with _lib.timed("facl_gemm_rs_wgrad %dx%dx%d%s" % (M, N, K, "" if amax is None else " h3")):
+            _lib.check(lib.facl_gemm_rs_wgrad(_lib.ptr(dy), _lib.ptr(y), M, N, K, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
+                                              _lib.ptr(amax), _lib.ptr(dW), _lib.ptr(slices), _lib.stream()), "facl_gemm_rs_wgrad")
         return dW
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     nz = max(1, min((M + 255) // 256, 512 // tiles))
@@ -624,9 +630,10 @@ class _Net3DV3(torch.autograd.Function):
         jobs = [(W1[:, 3:], False, W1[:, :3], h3), (W2, False, None, h3), (W3, False, None, h3)]
         want_bwd = training and backward_precision(ctx.prec) == "f32"
         if want_bwd:
-            jobs += [(W3, True, None), (W2, True, None), (W1[:, 3:], True, None)]
+            jobs += [(W3, True, None, BWD_H3), (W2, True, None, BWD_H3), (W1[:, 3:], True, None, BWD_H3)]
         pl = rs_planes_multi(jobs)
         ctx.bwd_planes = pl[3:] if want_bwd else None
+        ctx.bwd_h3 = want_bwd and BWD_H3
         y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws, h3)
         bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1)
         y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws, h3)
@@ -661,15 +668,20 @@ class _Net3DV3(torch.autograd.Function):
                                              _lib.ptr(bnc3), _lib.ptr(sums), _lib.ptr(ws), st), "facl_segmax_bwd_stats")
         dbe3, dga3, kk = _bn_bwd_consts(sums, C3, ctx.count, ctx.reduce_fn)
         dy = _lib.empty_like(y3)
-        _lib.check(lib.facl_segmax_bwd_apply(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
-                                             _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), st), "facl_segmax_bwd_apply")
+        # fp16x3 backward: max|dy| of each of the three gradient tensors, maintained by the kernel that writes it
+        h3 = ctx.bwd_h3 and bp == "f32"
+        amax = torch.zeros(3, _lib.AMAX_WORDS, dtype=torch.int32, device=y1.device) if h3 else None
+        am = (lambda i: amax[i]) if h3 else (lambda i: None)
+        _lib.check(lib.facl_segmax_bwd_apply_amax(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
+                                                  _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), _lib.ptr(am(0)), st),
+                   "facl_segmax_bwd_apply")
         bpl = ctx.bwd_planes if ctx.bwd_planes is not None else (None, None, None)
-        dW3 = _wgrad_pro(dy, y2, bnc2, bp)
+        dW3 = _wgrad_pro(dy, y2, bnc2, bp, am(0))
         # dgrad + the statistics pass of the next BatchNorm backward in one kernel (the tile is still in registers)
-        da, sums = _rs_dgrad(dy, W3, bp, bpl[0], y2, bnc2, ws)
+        da, sums = _rs_dgrad(dy, W3, bp, bpl[0], y2, bnc2, ws, am(0))
         # ---- layers 2 and 1: BN backward rows passes, weight gradient with the recomputed activation, dgrad
         grads = []
-        for y, bnc, yin, bnc_in, W in ((y2, bnc2, y1, bnc1, W2), (y1, bnc1, None, None, W1)):
+        for li, (y, bnc, yin, bnc_in, W) in enumerate(((y2, bnc2, y1, bnc1, W2), (y1, bnc1, None, None, W1)), 1):
             C = y.shape[1]
             if sums is None:
                 sums = _lib.empty((C, 2), **f64)
@@ -677,18 +689,18 @@ class _Net3DV3(torch.autograd.Function):
                            "facl_rows_bwd_stats")
             dbe, dga, kk = _bn_bwd_consts(sums, C, ctx.count, ctx.reduce_fn)
             dy = _lib.empty_like(y)
-            _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy), st),
-                       "facl_rows_bwd_apply")
+            _lib.check(lib.facl_rows_bwd_apply_amax(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
+                                                    _lib.ptr(am(li)), st), "facl_rows_bwd_apply")
             if yin is not None:
-                dW = _wgrad_pro(dy, yin, bnc_in, bp)
-                da, sums = _rs_dgrad(dy, W, bp, bpl[1], yin, bnc_in, ws)
+                dW = _wgrad_pro(dy, yin, bnc_in, bp, am(li))
+                da, sums = _rs_dgrad(dy, W, bp, bpl[1], yin, bnc_in, ws, am(li))
             else:                                                       # first layer: input = pooled | centres
                 dWh = gemm_wgrad(dy, pooled, prec=bp)
                 dWc = _lib.empty((C, 3), **f64)
                 _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(centers), P, C, _lib.ptr(dWc), _lib.ptr(ws), st),
                            "facl_rows_center_wgrad")
                 dW = torch.cat((dWc.float(), dWh), dim=1)
-                da = _rs_dgrad(dy, W[:, 3:], bp, bpl[2])[0] if ctx.needs_input_grad[0] else None
+                da = _rs_dgrad(dy, W[:, 3:], bp, bpl[2], amax=am(li))[0] if ctx.needs_input_grad[0] else None
             grads.append((dW, dga, dbe))
         (dW2, dga2, dbe2), (dW1, dga1, dbe1) = grads
         # d(bias) of a conv in front of a train-mode BN is identically zero: None leaves the parameter untouched

@@ -200,6 +200,17 @@ int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y,
                           int64_t M, int S, int C, const float* bnc, double* sums, void* ws, void* stream);
 int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                           int64_t M, int S, int C, const float* bnc, const float* kk, float* dy, void* stream);
+/* the two dy producers of the BatchNorm backward, also maintaining max|dy| in `amax`: a buffer of FACL_AMAX_WORDS uint32 the
+ * caller zeroed, in which the kernels raise one of 64 slots (one 128-byte line each: atomics on a single address serialise)
+ * to the bit pattern of the largest |dy| they wrote (non-negative floats order like unsigned integers; a NaN lands above
+ * everything); max|dy| = the maximum over the buffer.  The fp16x3 GEMMs that consume dy take its power-of-two operand scale
+ * from there, on the device, with no host round trip.  amax = null: the plain functions.  With amax the 4-channel kernels
+ * are required (C % 4 == 0, 16-byte aligned tensors), else FACL_E_ALIGN. */
+#define FACL_AMAX_WORDS 2048
+int facl_rows_bwd_apply_amax(const float* dout, const float* y, int64_t R, int C, const float* bnc, const float* kk,
+                             float* dy, uint32_t* amax, void* stream);
+int facl_segmax_bwd_apply_amax(const float* dxpre, const float* xpre, const float* y, const int32_t* arg, int64_t M, int S,
+                               int C, const float* bnc, const float* kk, float* dy, uint32_t* amax, void* stream);
 
 /* ---- fp32 MFMA GEMMs of the tail's dense 1x1 channel contractions (csrc/gemm.hip) ------------------
  * Weights are the checkpoint tensors, row-major (Cout,Cin) with leading dimension ldw (multiple of 4).
@@ -249,9 +260,14 @@ int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K
  *                            as facl_gemm_fwd; sgn / ymax / arg (all or none) as facl_gemm_fwd_segmax (M % 64 == 0)
  *   `half` (planes and forward): 0 = three bf16 planes, six products per multiply-add (bf16x6); 1 = two fp16 planes of the
  *                            operands pre-scaled by 2^8 (weights) / 2^4 (activations), THREE products (fp16x3, csrc/common.h):
- *                            the same fp32-GEMM accuracy (22-bit operands, fp32 accumulation) at half the MFMA work; forward
- *                            only (|a| < 4094, |w| < 255), the planes must have been built with the same `half`
- *   facl_gemm_rs_dgrad       da (M,K) = dy (M,N) W   (bf16x6 planes)
+ *                            the same fp32-GEMM accuracy (22-bit operands, fp32 accumulation) at half the MFMA work
+ *                            (|a| < 4094, |w| < 255: beyond that an fp16 piece overflows and the output is NaN, not a wrong
+ *                            number); the planes must have been built with the same `half`
+ *   facl_gemm_rs_dgrad       da (M,K) = dy (M,N) W.  half = 1: fp16x3 with dy's scale chosen per launch from `amax` (the
+ *                            FACL_AMAX_WORDS buffer of facl_rows_bwd_apply_amax / facl_segmax_bwd_apply_amax): the
+ *                            power of two that puts the maximum in [2^13, 2^14); elements down to 2^-16 of the maximum keep
+ *                            22 bits, smaller ones lose at most 2^-38 of the maximum
+ *   facl_gemm_rs_wgrad       amax non-null: the same arithmetic (dy by its dynamic scale, f(y) by 2^4)
  *   facl_gemm_wgrad_pro      dW (N,K) = dy^T relu(pscale*y + pshift): facl_gemm_wgrad whose `a` operand is recomputed from
  *                            the previous layer's raw output y (M,K) while it is staged (the companion of the forward
  *                            prologue: the activation tensor never exists); `_x3`: the opt-in three-product arithmetic.
@@ -266,7 +282,7 @@ int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, in
  * M >= 4096 and at least 8 output blocks): facl_gemm_rs_wgrad then returns FACL_E_CONFIG and callers use facl_gemm_wgrad[_pro]. */
 int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K);
 int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale, const float* pshift,
-                       float* dW, float* slices, void* stream);
+                       const uint32_t* amax, float* dW, float* slices, void* stream);
 int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
 int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, int half,
                         void* planes, void* stream);
@@ -278,11 +294,12 @@ int facl_gemm_rs_supported(int64_t M, int K, int N);
 int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, int N, const float* bias, const float* pscale,
                      const float* pshift, const float* centers, float* y, double* sums, const float* sgn, float* ymax,
                      int32_t* arg, void* ws, void* stream);
-int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int K, float* da, void* stream);
+int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int half, const uint32_t* amax, int K,
+                       float* da, void* stream);
 /* facl_gemm_rs_dgrad + facl_rows_bwd_stats(da, y, bnc) in one pass: sums (K,2) = the BatchNorm-backward column sums of the
  * layer whose activation relu(bn(y)) was this GEMM's forward input, taken from the accumulator tile before it is stored */
-int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, const void* planes, int K, float* da, const float* y,
-                               const float* bnc, double* sums, void* ws, void* stream);
+int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, const void* planes, int half, const uint32_t* amax, int K,
+                               float* da, const float* y, const float* bnc, double* sums, void* ws, void* stream);
 /* "bf16x3" twins (opt-in precision "x3"; never the default): each operand keeps its two leading bf16 pieces and a
  * multiply-add is three products (hi*mid, mid*hi, hi*hi) instead of six -- relative error of a product <= 3 * 2^-16
  * (results ~1e-5 of an fp64 GEMM; the north_star's tolerance for features / loss is 1e-4), half the MFMA work. */

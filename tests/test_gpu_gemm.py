@@ -253,7 +253,7 @@ def test_gemm_rs_dgrad_equals_gemm_dgrad_and_fp64(M, N, K):
     W = torch.randn(N, K, device=DEV, generator=g) / N ** 0.5
     planes = _rs_planes(lib, W, True)
     da, da2 = _lib.empty(M, K, device=DEV), _lib.empty(M, K, device=DEV)
-    _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), K, _lib.ptr(da), _lib.stream()), "rs_dgrad")
+    _lib.check(lib.facl_gemm_rs_dgrad(_lib.ptr(dy), M, N, _lib.ptr(planes), 0, None, K, _lib.ptr(da), _lib.stream()), "rs_dgrad")
     _lib.check(lib.facl_gemm_dgrad(_lib.ptr(dy), M, N, _lib.ptr(W), K, K, _lib.ptr(da2), _lib.stream()), "dgrad")
     ref = dy.double() @ W.double()
     assert rel_err(da.cpu().numpy(), ref.cpu().numpy()) < 2e-6
@@ -277,8 +277,8 @@ def test_gemm_rs_dgrad_bnstats_equals_the_rows_pass(M, N, K):
     p = _lib.ptr
     da, da2 = _lib.empty(M, K, device=DEV), _lib.empty(M, K, device=DEV)
     sums, sums2 = _lib.empty(K, 2, dtype=torch.float64, device=DEV), _lib.empty(K, 2, dtype=torch.float64, device=DEV)
-    _lib.check(lib.facl_gemm_rs_dgrad_bnstats(p(dy), M, N, p(planes), K, p(da), p(y), p(bnc), p(sums), p(_ws()), _lib.stream()), "bnstats")
-    _lib.check(lib.facl_gemm_rs_dgrad(p(dy), M, N, p(planes), K, p(da2), _lib.stream()), "dgrad")
+    _lib.check(lib.facl_gemm_rs_dgrad_bnstats(p(dy), M, N, p(planes), 0, None, K, p(da), p(y), p(bnc), p(sums), p(_ws()), _lib.stream()), "bnstats")
+    _lib.check(lib.facl_gemm_rs_dgrad(p(dy), M, N, p(planes), 0, None, K, p(da2), _lib.stream()), "dgrad")
     assert torch.equal(da, da2)
     _lib.check(lib.facl_rows_bwd_stats(p(da), p(y), M, K, p(bnc), p(sums2), p(_ws()), _lib.stream()), "rows_bwd_stats")
     d = torch.where(bnc[2] * y + bnc[3] > 0, da, torch.zeros_like(da)).double()
@@ -305,7 +305,7 @@ def test_gemm_rs_wgrad_vs_fp64_and_staged_kernel(M, N, K, pro):
     pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
     dW, sl = _lib.empty(N, K, device=DEV), _lib.empty(nz * N * K, device=DEV)
     p = _lib.ptr
-    _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y), M, N, K, p(ps), p(pt), p(dW), p(sl), _lib.stream()), "rs_wgrad")
+    _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y), M, N, K, p(ps), p(pt), None, p(dW), p(sl), _lib.stream()), "rs_wgrad")
     a = torch.relu(y * ps + pt) if pro else y
     a64 = torch.relu(y.double() * ps.double() + pt.double()) if pro else y.double()
     ref = dy.double().t() @ a64
@@ -363,3 +363,102 @@ def test_gemm_rs_fwd_fp16x3_is_fp32_grade(M, K, N, pro, ctr, seg):
         sy = (y * torch.where(sgn < 0, -1.0, 1.0)).view(M // 64, 64, N)
         assert torch.equal(ymax, sy.max(dim=1).values)
         assert torch.equal(arg.long(), (sy == ymax.unsqueeze(1)).float().argmax(dim=1))
+
+
+def _bn_consts(K, g):
+    return torch.stack((torch.randn(K, device=DEV, generator=g) * 0.1, torch.rand(K, device=DEV, generator=g) + 0.5,
+                        torch.randn(K, device=DEV, generator=g), torch.randn(K, device=DEV, generator=g) * 0.3,
+                        torch.zeros(K, device=DEV))).contiguous()                     # mean | invstd | scale | shift | (unused)
+
+
+def _clear_of_the_relu_edge(y, bnc):
+    """Entries whose scale*y + shift is within rounding of 0 would open or close the ReLU depending on fma vs mul+add; the
+    reference expression below is not the kernel's instruction sequence, so move them well inside the open side."""
+    t = bnc[2].double() * y.double() + bnc[3].double()
+    return torch.where(t.abs() < 1e-4, ((1.0 - bnc[3]) / bnc[2]).expand_as(y), y).contiguous()
+
+
+@pytest.mark.parametrize("mag", [1.0, 3e-9, 7e5])
+@pytest.mark.parametrize("M,N,K", [(8100, 1024, 512), (8192, 256, 256)])
+def test_gemm_rs_backward_fp16x3_dynamic_scale(M, N, K, mag):
+    """Backward fp16x3: the gradient operand's power-of-two scale is chosen on the device from max|dy|, which the kernel that
+    WRITES dy maintains (facl_rows_bwd_apply_amax).  Gradients of magnitude 3e-9 .. 7e5 with a heavy tail (a few entries
+    1000x the rest) and a band of exact zeros: the published maximum is exact, dgrad (+ fused BatchNorm-backward sums) and
+    the weight gradient meet the bf16x6 kernels' fp64 bounds."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    p = _lib.ptr
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    # dy comes out of the BatchNorm-backward rows pass, as in the model
+    dout = torch.randn(M, N, device=DEV, generator=g) * mag
+    dout[::97, ::13] *= 1000.0
+    dout[:, 5::17] = 0.0
+    yprev = torch.randn(M, N, device=DEV, generator=g)
+    bnc_n = _bn_consts(N, g)
+    kk = torch.randn(2, N, device=DEV, generator=g) * (1e-3 * mag)
+    dy, dy2 = _lib.empty(M, N, device=DEV), _lib.empty(M, N, device=DEV)
+    amax = torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device=DEV)
+    _lib.check(lib.facl_rows_bwd_apply_amax(p(dout), p(yprev), M, N, p(bnc_n), p(kk), p(dy), p(amax), _lib.stream()), "apply_amax")
+    _lib.check(lib.facl_rows_bwd_apply(p(dout), p(yprev), M, N, p(bnc_n), p(kk), p(dy2), _lib.stream()), "apply")
+    assert torch.equal(dy, dy2)
+    assert float(amax.view(torch.float32).max()) == float(dy.abs().max())
+    # ---- dgrad (+ BN-backward sums)
+    W = torch.randn(N, K, device=DEV, generator=g) / N ** 0.5
+    bnc = _bn_consts(K, g)
+    y = _clear_of_the_relu_edge(torch.randn(M, K, device=DEV, generator=g), bnc)
+    ref = dy.double() @ W.double()
+    das = {}
+    for half in (1, 0):
+        planes = _rs_planes(lib, W, True, None, half)
+        da, da2 = _lib.empty(M, K, device=DEV), _lib.empty(M, K, device=DEV)
+        sums = _lib.empty(K, 2, dtype=torch.float64, device=DEV)
+        am = p(amax) if half else None
+        _lib.check(lib.facl_gemm_rs_dgrad(p(dy), M, N, p(planes), half, am, K, p(da), _lib.stream()), "dgrad")
+        _lib.check(lib.facl_gemm_rs_dgrad_bnstats(p(dy), M, N, p(planes), half, am, K, p(da2), p(y), p(bnc), p(sums), p(_ws()),
+                                                  _lib.stream()), "bnstats")
+        assert torch.equal(da, da2)
+        das[half] = (rel_err(da.cpu().numpy(), ref.cpu().numpy()), sums)
+    print(f"dgrad fp16x3 {das[1][0]:.2e}   bf16x6 {das[0][0]:.2e}")
+    assert das[1][0] < 2e-6 and das[1][0] < 2.0 * das[0][0]
+    d = torch.where(bnc[2] * y + bnc[3] > 0, ref, torch.zeros_like(ref))
+    yhat = ((y - bnc[0]) * bnc[1]).double()
+    refs = torch.stack((d.sum(0), (d * yhat).sum(0)), 1)
+    scale = torch.stack((d.abs().sum(0), (d * yhat).abs().sum(0)), 1).clamp_min(1e-300)
+    assert float(((das[1][1] - refs).abs() / scale).max()) < 2e-6
+    assert lib.facl_gemm_rs_dgrad(p(dy), M, N, p(planes), 1, None, K, p(da), _lib.stream()) == -2      # FACL_E_NULL: fp16x3 needs the maximum
+    # ---- weight gradient dW (N,K2) = dy^T relu(bn(y2)) where the register-streamed kernel serves the shape
+    K2 = 512
+    nz = lib.facl_gemm_rs_wgrad_slices(M, N, K2)
+    if nz >= 1:
+        y2 = torch.randn(M, K2, device=DEV, generator=g) * 3.0
+        ps, pt = torch.rand(K2, device=DEV, generator=g) + 0.5, torch.randn(K2, device=DEV, generator=g) * 0.3
+        refw = dy.double().t() @ torch.relu(y2.double() * ps.double() + pt.double())
+        errs = {}
+        for half in (1, 0):
+            dW, sl = _lib.empty(N, K2, device=DEV), _lib.empty(nz * N * K2, device=DEV)
+            _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y2), M, N, K2, p(ps), p(pt), p(amax) if half else None, p(dW), p(sl),
+                                              _lib.stream()), "rs_wgrad")
+            errs[half] = rel_err(dW.cpu().numpy(), refw.cpu().numpy())
+        print(f"wgrad fp16x3 {errs[1]:.2e}   bf16x6 {errs[0]:.2e}")
+        assert errs[1] < 3e-6 and errs[1] < 2.0 * errs[0]
+
+
+def test_segmax_bwd_apply_amax_publishes_the_exact_maximum():
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    p = _lib.ptr
+    g = torch.Generator(device=DEV).manual_seed(5)
+    Mc, S, C = 96, 64, 1024
+    y = torch.randn(Mc * S, C, device=DEV, generator=g)
+    xpre = torch.randn(Mc, C, device=DEV, generator=g)
+    dxpre = torch.randn(Mc, C, device=DEV, generator=g) * 1e-4
+    arg = torch.randint(0, S, (Mc, C), device=DEV, generator=g, dtype=torch.int32)
+    bnc = _bn_consts(C, g)
+    kk = torch.randn(2, C, device=DEV, generator=g) * 1e-7
+    dy, dy2 = _lib.empty(Mc * S, C, device=DEV), _lib.empty(Mc * S, C, device=DEV)
+    amax = torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device=DEV)
+    _lib.check(lib.facl_segmax_bwd_apply_amax(p(dxpre), p(xpre), p(y), p(arg), Mc, S, C, p(bnc), p(kk), p(dy), p(amax),
+                                              _lib.stream()), "segmax_apply_amax")
+    _lib.check(lib.facl_segmax_bwd_apply(p(dxpre), p(xpre), p(y), p(arg), Mc, S, C, p(bnc), p(kk), p(dy2), _lib.stream()), "segmax_apply")
+    assert torch.equal(dy, dy2)
+    assert float(amax.view(torch.float32).max()) == float(dy.abs().max())

@@ -38,7 +38,7 @@ for K, N in ((256, 256), (256, 512), (512, 1024)):
     # dgrad of this layer: dy (M,N) W (N,K) -> (M,K)
     dy = torch.randn(M, N, device=DEV); da = torch.empty(M, K, device=DEV)
     plt = planes_of(W, True)
-    g_rs = lambda: _lib.check(lib.facl_gemm_rs_dgrad(p(dy), M, N, p(plt), K, p(da), st), "rsd")
+    g_rs = lambda: _lib.check(lib.facl_gemm_rs_dgrad(p(dy), M, N, p(plt), 0, None, K, p(da), st), "rsd")
     g_sb = lambda: _lib.check(lib.facl_gemm_dgrad(p(dy), M, N, p(W), K, K, p(da), st), "sbd")
     for r in range(2):
         t1, t2 = timeit(g_rs), timeit(g_sb)

@@ -139,6 +139,7 @@ def kernel_models(a, K=64):
     sa_f32 = os.environ.get("FACL_SA_F32") == "1"
     bwd2_f32 = os.environ.get("FACL_BWD2_F32") == "1"
     y2 = 64 * 64 * 4                                   # one (64 pos x 64 ch) fp32 tile
+    fwd_h3 = os.environ.get("FACL_FWD_H3", "1") != "0"  # forward arithmetic of facl_sa_fwd3 / the row-streamed GEMMs (sa_mlp.py)
     return {
         # FPS (when --fps 1): the cloud's xyz read once, m = S picks written; the S-1 passes over the cloud stay on chip
         "facl_fps": dict(kernel="k_fps", flops=M * S * a.N * 9.0, pipe="valu", bytes=M * (a.N * D * 4.0 + S * 4.0)),
@@ -148,7 +149,8 @@ def kernel_models(a, K=64):
                              flops=nunits * 2.0 * 64 * 64 * 64, bytes=nunits * (64 * D * 4.0 + y2)),
         "facl_sa_fwd3": dict(kernel="k_sa_fwd3_sb<fp16>" if a.config == "dense" else ("k_sa_fwd3" if sa_f32 else
                                     "k_sa_fwd3_sb<x3>" if getattr(a, "precision", "f32") == "x3" else "k_sa_fwd3_sb"),
-                             pipe="f16" if a.config == "dense" else ("f32" if sa_f32 else "bf16x3" if getattr(a, "precision", "f32") == "x3" else "bf16x6"),
+                             pipe="f16" if a.config == "dense" else ("f32" if sa_f32 else "bf16x3" if getattr(a, "precision", "f32") == "x3"
+                                                                     else "fp16x3" if fwd_h3 else "bf16x6"),
                              flops=nunits * 2.0 * 64 * 64 * 256, bytes=nunits * (y2 + 1024.0 + 256.0)),
         "facl_sa_bwd1": dict(kernel="k_sa_bwd1", pipe="f32", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
                              bytes=nunits * (2.0 * y2 + 1024 + 256)),
@@ -166,7 +168,8 @@ def _gemm_model(label):
     kind, dims = parts[0], parts[1]
     m, k, n = (int(v) for v in dims.split("x"))
     tag = parts[2] if len(parts) > 2 else ""
-    pipe = "f16" if tag == "f16" else "bf16x3" if tag == "x3" else ("f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6")
+    pipe = "f16" if tag == "f16" else "bf16x3" if tag == "x3" else "fp16x3" if tag == "h3" else \
+        ("f32" if os.environ.get("FACL_GEMM_F32") == "1" else "bf16x6")
     name = {"facl_gemm_fwd": "k_gemm_sb fwd", "facl_gemm_dgrad": "k_gemm_sb dgrad", "facl_gemm_wgrad": "k_gemm_sb wgrad",
             "facl_gemm_rs_fwd": "k_gemm_rs fwd", "facl_gemm_rs_dgrad": "k_gemm_rs dgrad", "facl_gemm_rs_wgrad": "k_wgrad_rs wgrad"}[kind]
     return dict(kernel="%s %s%s" % (name, dims, " (fp16 inputs)" if pipe == "f16" else " (bf16x3)" if pipe == "bf16x3" else ""),
@@ -177,8 +180,8 @@ def _gemm_model(label):
 def price(model, ms):
     """One roofline record: both roofs are evaluated, `bound` is the one that allows the LONGER time at its peak."""
     sec = ms * 1e-3
-    ex = model["flops"] * {"bf16x6": 6.0, "bf16x3": 3.0}.get(model["pipe"], 1.0)
-    peak_tf = PEAK_MFMA_BF16_TFLOPS if model["pipe"] in ("bf16x6", "bf16x3", "f16") else PEAK_MFMA_F32_TFLOPS
+    ex = model["flops"] * {"bf16x6": 6.0, "bf16x3": 3.0, "fp16x3": 3.0}.get(model["pipe"], 1.0)
+    peak_tf = PEAK_MFMA_BF16_TFLOPS if model["pipe"] in ("bf16x6", "bf16x3", "fp16x3", "f16") else PEAK_MFMA_F32_TFLOPS
     t_mfma = ex / (peak_tf * 1e12) if model["pipe"] != "valu" else 0.0
     t_hbm = model["bytes"] / (PEAK_HBM_GBPS * 1e9)
     rec = {"kernel": model["kernel"], "ms_per_launch": round(ms, 4)}
@@ -192,6 +195,8 @@ def price(model, ms):
                algorithmic_tflops=round(model["flops"] / sec / 1e12, 1), hbm_frac=round(model["bytes"] / sec / 1e9 / PEAK_HBM_GBPS, 4))
     if model["pipe"] == "bf16x6":
         rec["executed_bf16_flops_per_launch"] = ex
+    if model["pipe"] == "fp16x3":
+        rec["executed_fp16_flops_per_launch"] = ex
     return rec
 
 

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int i = 0; i < 4; ++i) xv[ct][i] = xn[ct][i];
-        if (u + nwaves < nunits) load_x(u + nwaves, xn);
+        load_x(u + nwaves < nunits ? u + nwaves : u, xn);   // unconditional: a conditional prefetch is waited for on the spot (see k_sa_fwd3_sb)
         // layer 1 on the VALU for this lane's two positions, straight into the bf16 planes of the B operand
         bf16x8 ap[2][4][3];                  // [position tile][k16 block][plane]
 #pragma unroll
@@ -525,15 +525,21 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
     if (threadIdx.x < 16) {
-        sc2s[threadIdx.x] = reinterpret_cast<const float4*>(sc2)[threadIdx.x];
-        sh2s[threadIdx.x] = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
+        float4 a = reinterpret_cast<const float4*>(sc2)[threadIdx.x], b = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
+        if (NP == 4) {                                       // relu(16 s y + 16 t) = 16 relu(s y + t) exactly: the activation scale is free
+            a.x *= FACL_H3_SA; a.y *= FACL_H3_SA; a.z *= FACL_H3_SA; a.w *= FACL_H3_SA;
+            b.x *= FACL_H3_SA; b.y *= FACL_H3_SA; b.z *= FACL_H3_SA; b.w *= FACL_H3_SA;
+        }
+        sc2s[threadIdx.x] = a;
+        sh2s[threadIdx.x] = b;
     }
-    // fp16x3 accumulates (a 2^4)(w 2^8): the bias enters at that scale and the reductions are scaled back at the end
-    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn_of(sgn3[threadIdx.x]) * (NP == 4 ? 4096.0f : 1.0f);
+    // fp16x3: the accumulators start at 0 (an inline constant: no 32 register moves per tile) and hold u = y - bias scaled by
+    // 2^12; the bias joins the maximum in the epilogue and the statistics once, in fp64, when the partial row is written
+    if (threadIdx.x < 256) b3s[threadIdx.x] = b3[threadIdx.x] * sgn_of(sgn3[threadIdx.x]);
     __syncthreads();
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
-    const int wave_g = blockIdx.x * 8 + (threadIdx.x >> 6), nwaves = gridDim.x * 8;
+    const int wave_g = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + (threadIdx.x >> 6)), nwaves = gridDim.x * 8;   // uniform: scalar addresses
 #pragma unroll
     for (int i = 0; i < 4; ++i) stat[i * 64 + lane] = make_double2(0.0, 0.0);
 
@@ -544,7 +550,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
     };
     if (wave_g < nunits) issue_loads(wave_g);
-    for (int u = wave_g; u < nunits; u += nwaves) {
+    int nun = 0;
+    for (int u = wave_g; u < nunits; u += nwaves, ++nun) {
         bf16x8 ap[2][4][3];                  // [position tile][k16 block][plane]
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -557,8 +564,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                     const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
                     const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
                     if (NP == 4) {
-                        split_pair_h(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f) * FACL_H3_SA, fmaxf(fmaf(sc.y, y.y, sh.y), 0.f) * FACL_H3_SA, hi[2 * t], mi[2 * t]);
-                        split_pair_h(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f) * FACL_H3_SA, fmaxf(fmaf(sc.w, y.w, sh.w), 0.f) * FACL_H3_SA, hi[2 * t + 1], mi[2 * t + 1]);
+                        split_pair_h(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t]);
+                        split_pair_h(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1]);
                         lo[2 * t] = lo[2 * t + 1] = 0u;
                     } else if (NP >= 2) {
                         split_pair(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t], lo[2 * t]);
@@ -573,11 +580,14 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                 ap[ct][kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
                 ap[ct][kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
             }
-        if (u + nwaves < nunits) issue_loads(u + nwaves);
-#pragma unroll 1
-        for (int ct3 = 0; ct3 < 8; ++ct3) {
-            const float bias = b3s[32 * ct3 + q];
-            f32x16 acc0, acc1;
+        // unconditional (the last round re-reads its own unit, an L2 hit): under `if (u + nwaves < nunits)` the register
+        // allocator merged the loaded / not-loaded values with copies OUT of the freshly loaded registers, behind an
+        // s_waitcnt vmcnt(8) -- every wave stalled for a full memory round trip per unit (~100 us of the kernel's 360)
+        issue_loads(u + nwaves < nunits ? u + nwaves : u);
+        // One column tile (32 channels) = 8 / 12 / 24 MFMAs into two accumulators (the unit's two position tiles), then an
+        // epilogue of ~130 VALU instructions on them.
+        auto mma_tile = [&](int ct3, f32x16& acc0, f32x16& acc1) {
+            const float bias = NP == 4 ? 0.f : b3s[32 * ct3 + q];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = bias; }
             constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
@@ -612,43 +622,79 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, ap[1][kk][0]), wb, acc1, 0, 0, 0);
                 }
             }
-            float s = 0.f, sq = 0.f, best = acc0[0];
-            int bp = 0;
+        };
+        struct Epi { float s, sq, best; int bp; };
+        auto epi_compute = [&](int ct3, const f32x16& acc0, const f32x16& acc1) -> Epi {
+            // two interleaved sum chains; the maximum with v_max3_f32, then its FIRST position without
+            // compares (a v_cmp -> v_cndmask chain costs a hazard nop per value): d = v - best is <= 0 and exactly +0 where v is
+            // the maximum, so bits(d) | position is the position there and >= 2^31 elsewhere; the unsigned minimum is the answer
+            float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+            float best = acc0[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc0[r];
-                s += v; sq = fmaf(v, v, sq);
-                if (v > best) { best = v; bp = rowmap(r, 0); }
+            for (int r = 0; r < 16; r += 2) {                   // scalar on purpose: packed f32 VALU is slow beside MFMAs (MI355X guide)
+                s2.x += acc0[r]; s2.y += acc0[r + 1]; q2.x = fmaf(acc0[r], acc0[r], q2.x); q2.y = fmaf(acc0[r + 1], acc0[r + 1], q2.y);
+                s2.x += acc1[r]; s2.y += acc1[r + 1]; q2.x = fmaf(acc1[r], acc1[r], q2.x); q2.y = fmaf(acc1[r + 1], acc1[r + 1], q2.y);
+                best = fmaxf(fmaxf(best, acc0[r]), acc0[r + 1]);
+                best = fmaxf(fmaxf(best, acc1[r]), acc1[r + 1]);
             }
+            unsigned key = 0xffffffffu;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc1[r];
-                s += v; sq = fmaf(v, v, sq);
-                if (v > best) { best = v; bp = 32 + rowmap(r, 0); }
+            for (int r = 0; r < 16; r += 2) {
+                const unsigned k0 = __float_as_uint(acc0[r] - best) | (unsigned)rowmap(r, 0), k1 = __float_as_uint(acc0[r + 1] - best) | (unsigned)rowmap(r + 1, 0);
+                const unsigned k2 = __float_as_uint(acc1[r] - best) | (unsigned)(32 + rowmap(r, 0)), k3 = __float_as_uint(acc1[r + 1] - best) | (unsigned)(32 + rowmap(r + 1, 0));
+                key = min(min(key, k0), k1);
+                key = min(min(key, k2), k3);
             }
-            if (NP == 4) { s *= FACL_H3_UNSCALE; sq *= FACL_H3_UNSCALE * FACL_H3_UNSCALE; best *= FACL_H3_UNSCALE; }   // exact: powers of two
+            int bp = (int)(key & 63u);
+            float s = s2.x + s2.y, sq = q2.x + q2.y;
+            if (NP == 4) {                                      // exact rescale (powers of two); statistics stay those of u = y - bias
+                s *= FACL_H3_UNSCALE; sq *= FACL_H3_UNSCALE * FACL_H3_UNSCALE;
+                best = fmaf(best, FACL_H3_UNSCALE, b3s[32 * ct3 + q]);
+            }
             bp += 4 * h;
-            const float ob = __shfl_xor(best, 32, 64);
-            const int op = __shfl_xor(bp, 32, 64);
+            return Epi{s, sq, best, bp};
+        };
+        // The two lane halves hold the two position halves of a channel: lanes 0..31 fetch their partner's (lane + 32) results
+        // with v_permlane32_swap (a VALU instruction: ds_bpermute would park the wave on an LDS round trip per tile) and update
+        // the wave's fp64 statistics with no-return LDS atomics (ds_add_f64: no read to wait for either).
+        auto upper = [&](unsigned x) { return __builtin_amdgcn_permlane32_swap(x, x, false, false)[1]; };
+        auto epi_store = [&](int ct3, const Epi& e) {
+            float best = e.best;
+            int bp = e.bp;
+            const float ob = __uint_as_float(upper(__float_as_uint(best)));
+            const int op = (int)upper((unsigned)bp);
             if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }   // first max wins (MaxPool2d)
             if (part) {
-                const float st = s + __shfl_xor(s, 32, 64), sqt = sq + __shfl_xor(sq, 32, 64);
+                const float st = e.s + __uint_as_float(upper(__float_as_uint(e.s))), sqt = e.sq + __uint_as_float(upper(__float_as_uint(e.sq)));
                 if (h == 0) {
-                    double2 d = stat[ct3 * 32 + q];
-                    d.x += (double)st; d.y += (double)sqt;
-                    stat[ct3 * 32 + q] = d;
+                    double* d = reinterpret_cast<double*>(stat + ct3 * 32 + q);
+                    __hip_atomic_fetch_add(d, (double)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(d + 1, (double)sqt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
             if (h == 0) {
                 ymax[(size_t)u * 256 + 32 * ct3 + q] = best;
                 arg[(size_t)u * 256 + 32 * ct3 + q] = (unsigned char)bp;
             }
+        };
+        // (tried on this loop, measured equal within 1-2 %: the next tile's MFMAs interleaved by hand with this tile's epilogue
+        // in the wave; waves 4..7 running one MFMA phase ahead of their SIMD partners; B fragments requested a k-block ahead)
+        f32x16 a0, a1;
+#pragma unroll 1
+        for (int ct3 = 0; ct3 < 8; ++ct3) {
+            mma_tile(ct3, a0, a1);
+            epi_store(ct3, epi_compute(ct3, a0, a1));
         }
     }
     if (part && h == 0) {
 #pragma unroll
         for (int ct3 = 0; ct3 < 8; ++ct3) {
-            const double2 st = stat[ct3 * 32 + q];
+            double2 st = stat[ct3 * 32 + q];
+            if (NP == 4) {                       // sums of u = y - bias over n positions -> sums of y
+                const double b = (double)b3s[32 * ct3 + q], n = 64.0 * (double)nun;
+                st.y += 2.0 * b * st.x + n * b * b;
+                st.x += n * b;
+            }
             part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q)] = st.x * (double)sgn_of(sgn3[32 * ct3 + q]);   // statistics of y3, not of sgn3*y3
             part[(size_t)wave_g * 512 + 2 * (32 * ct3 + q) + 1] = st.y;
         }

@@ -45,8 +45,8 @@ def main():
                  "shape": {"B": 32, "T": 24, "N": 2048, "D": 3}, "build": tag,
                  "k_sa_bwd1": pick("k_sa_bwd1"), "k_sa_bwd2_sb": pick("k_sa_bwd2_sb"), "k_sa_bwd_w3": pick("k_sa_bwd_w3"),
                  "k_sa_fwd3_sb": pick("k_sa_fwd3_sb"), "k_sa_fwd2_sb": pick("k_sa_fwd2_sb"), "k_group": pick("k_group"),
-                 "k_gemm_rs fwd 49152x512x1024": pick("k_gemm_rs<true, true, false>"),
-                 "k_gemm_rs fwd 49152x256x512": pick("k_gemm_rs<true, false, false>"),
+                 "k_gemm_rs fwd 49152x512x1024": pick("k_gemm_rs<true, true, false"),
+                 "k_gemm_rs fwd 49152x256x512": pick("k_gemm_rs<true, false, false"),
                  "k_wgrad_rs wgrad 49152x1024x512": pick("k_wgrad_rs")}
         json.dump({k: v for k, v in table.items() if v is not None}, open(os.path.join(pr, "pmc_traffic.json"), "w"), indent=1)
     mj = os.path.join(go, f"pmc_{tag}_mfma_util.json")
@@ -57,8 +57,8 @@ def main():
                "shape": {"B": 32, "T": 24, "N": 2048, "D": 3}, "build": tag}
         for name, pre in (("k_sa_fwd3_sb", "k_sa_fwd3_sb"), ("k_sa_bwd1", "k_sa_bwd1"), ("k_sa_bwd_w3", "k_sa_bwd_w3"),
                           ("k_sa_bwd2_sb", "k_sa_bwd2_sb"), ("k_sa_fwd2_sb", "k_sa_fwd2_sb"),
-                          ("k_gemm_rs fwd 49152x512x1024", "k_gemm_rs<true, true, false>"),
-                          ("k_gemm_rs fwd 49152x256x512", "k_gemm_rs<true, false, false>"),
+                          ("k_gemm_rs fwd 49152x512x1024", "k_gemm_rs<true, true, false"),
+                          ("k_gemm_rs fwd 49152x256x512", "k_gemm_rs<true, false, false"),
                           ("k_wgrad_rs wgrad 49152x1024x512", "k_wgrad_rs")):
             v = pick(pre)
             if v:
@@ -101,8 +101,8 @@ Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-ste
 ## Roofline section of `{tag}_bench_line.json` (every heavy entry, timed inside the step)
 
 {tbl}
-`roofline` = the first row (the longest kernel).  bf16x6 kernels are priced with the bf16 FLOPs they execute (6 per
-algorithmic multiply-add) against 2,500 TFLOP/s; fp32-MFMA kernels (`k_sa_bwd1`, `k_sa_bwd_w3`) with algorithmic FLOPs against
+`roofline` = the first row (the longest kernel).  bf16x6 / fp16x3 kernels are priced with the bf16 / fp16 FLOPs they execute
+(6 / 3 per algorithmic multiply-add) against 2,500 TFLOP/s; fp32-MFMA kernels (`k_sa_bwd1`, `k_sa_bwd_w3`) with algorithmic FLOPs against
 157.3 TFLOP/s; PMC traffic from `profiles/pmc_traffic.json` (offline `--pmc FETCH_SIZE` / `WRITE_SIZE` passes of this build:
 `{tag}_pmc_traffic.md`); MFMA-pipe utilisation and the waves' cycle breakdown from the same call: `{tag}_pmc_mfma_util.md`,
 `{tag}_pmc_wave_cycles.md`.

@@ -70,6 +70,7 @@ def main():
       return {
         "fwd2": (lambda: lib.facl_sa_fwd2(p(x), nunits, D, p(l1tab), p(W2), p(b2), p(dz2f), p(s64), p(ws), st), F),
         "fwd3": (lambda: lib.facl_sa_fwd3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), st), 4 * F),
+        "fwd3h": (lambda: lib.facl_sa_fwd3_h3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), st), 4 * F),
         "bwd0": (lambda: lib.facl_sa_bwd0(p(coef), p(ymax), nunits, p(bnc3), p(coef), p(s256), p(ws), st), 0),
         "bwd1": (lambda: lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg), p(dz2f), p(s64), p(ws), st), F),
         "bwd_w3": (lambda: lib.facl_sa_bwd_w3(p(y2f), nunits, p(bnc2), p(coef), p(arg), p(o3), p(ws), st), 0.75 * F),

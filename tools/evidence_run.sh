@@ -17,6 +17,8 @@ timeout -k 10 300 python bench.py --precision x3b --no-cpu-baseline | tail -n 1 
 timeout -k 10 300 python bench.py --precision x3 --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_optin_x3.json"
 FACL_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --B 16 --no-cpu-baseline | tail -n 1 > "$O/${TAG}_bench_2rank_gloo_rehearsal.json"
 echo bench lines done
+# `lines` as second argument: only refresh the bench lines (e.g. after profiles/pmc_*.json were regenerated from this build)
+if [ "$2" = "lines" ]; then exit 0; fi
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$TAG" -o r -- python3 "$R/bench.py" > "$O/prof_${TAG}_bench.log" 2>&1

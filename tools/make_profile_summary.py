@@ -72,12 +72,13 @@ def main():
     steps = 3 + d_steps(L["bench_line"])
     d = L["bench_line"]
     summ = open(os.path.join(go, f"prof_{tag}_summary.txt")).read()
-    tbl = ("| kernel | ms/launch (in-step HIP events) | bound | achieved | peak | frac | hbm_frac | PMC traffic / algorithmic bytes |\n"
-           "|---|---|---|---|---|---|---|---|\n")
+    tbl = ("| kernel | ms/launch (in-step HIP events) | arithmetic | bound | achieved (executed) | peak | frac | algorithmic TFLOP/s | hbm_frac | PMC traffic / algorithmic bytes |\n"
+           "|---|---|---|---|---|---|---|---|---|---|\n")
     for r in ([d["roofline"]] + d["roofline_more"])[:16]:
         tr = ("%.2f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "-"
-        tbl += "| `%s` | %.4f | %s | %.1f %s | %.0f | %.3f | %.3f | %s |\n" % (
-            r["kernel"], r["ms_per_launch"], r["bound"], r["achieved"], r["unit"], r["peak"], r["frac"], r["hbm_frac"], tr)
+        tbl += "| `%s` | %.4f | %s | %s | %.1f %s | %.0f | %.3f | %.1f | %.3f | %s |\n" % (
+            r["kernel"], r["ms_per_launch"], r.get("pipe", "-"), r["bound"], r["achieved"], r["unit"], r["peak"], r["frac"],
+            r.get("algorithmic_tflops", 0.0), r["hbm_frac"], tr)
     optin_rows = "".join(
         f'| `python bench.py --precision {n.split("_")[-1]}` (OPT-IN arithmetic, not the headline: DESIGN 3.0) | {L[n]["ms_per_step"]} | '
         f'{L[n]["value"]} | `{tag}_{n}.json` |\n' for n in optin)
@@ -102,7 +103,8 @@ Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-ste
 
 {tbl}
 `roofline` = the first row (the longest kernel).  bf16x6 / fp16x3 kernels are priced with the bf16 / fp16 FLOPs they execute
-(6 / 3 per algorithmic multiply-add) against 2,500 TFLOP/s; fp32-MFMA kernels (`k_sa_bwd1`, `k_sa_bwd_w3`) with algorithmic FLOPs against
+(6 / 3 per algorithmic multiply-add) against 2,500 TFLOP/s -- a kernel that moved from bf16x6 to fp16x3 executes half the FLOPs,
+so its `frac` falls while its time and its algorithmic (fp32-equivalent) TFLOP/s improve: compare that column across rounds; fp32-MFMA kernels (`k_sa_bwd1`, `k_sa_bwd_w3`) with algorithmic FLOPs against
 157.3 TFLOP/s; PMC traffic from `profiles/pmc_traffic.json` (offline `--pmc FETCH_SIZE` / `WRITE_SIZE` passes of this build:
 `{tag}_pmc_traffic.md`); MFMA-pipe utilisation and the waves' cycle breakdown from the same call: `{tag}_pmc_mfma_util.md`,
 `{tag}_pmc_wave_cycles.md`.

@@ -44,7 +44,11 @@ def parse():
                          "(~1e-5 relative per GEMM); x3b: three products in the BACKWARD GEMMs only (features / loss unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fps", type=int, default=0, help="1: FPS-reorder the views on the GPU inside the timed step")
-    ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (single GPU only)")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step as HIP graph(s): one graph on a single GPU, graph "
+                                                         "segments cut at every collective under data parallelism")
+    ap.add_argument("--rehearse-dp", type=int, default=0,
+                    help="1 (with --gpus 1): run the data-parallel code path on a 1-rank RCCL group -- every collective of the "
+                         "N>1 step executes (as an identity) -- to time that path on a one-GPU box; never the headline")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
     a = ap.parse_args()
     dflt = {"motion": (32, 24, 2048), "appearance": (32, 24, 2048), "dense": (8, 32, 4096)}[a.config]
@@ -307,6 +311,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rank, world = fdist.init_from_env()
+    if a.rehearse_dp and world == 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
+        tdist.init_process_group("nccl", rank=0, world_size=1)
+        fdist.is_distributed = lambda: True                 # is_distributed() is world_size > 1: force the hooks on
+        import facl_amd.train_common as _tc
+        _tc.fdist.is_distributed = fdist.is_distributed
     if world != a.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
         sys.exit(2)
@@ -326,7 +338,7 @@ def main():
         net = PointNet_Plus(opt, gost=a.T).to(dev).train()
         net.precision = a.precision
         net.bn_reduce_fn = fdist.make_bn_reduce_fn()
-        use_graph = bool(a.graph) and world == 1
+        use_graph = bool(a.graph)              # world > 1: the capture is cut at every collective (facl_amd/dist.py: GraphSegments)
         from facl_amd.optim import FusedAdam
         optim = FusedAdam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)     # cn3d_train_motion_GL.py:180, one launch
         step = ContrastiveStep(net, optim, opt, a.T, fps_reorder=bool(a.fps))
@@ -339,7 +351,9 @@ def main():
         if use_graph:
             try:
                 step = GraphedStep(step, batches[0], a.T)
-                mode = "hipgraph"
+                mode = "hipgraph" if step.segments is None else \
+                    "hipgraph segments (%d graphs, %d eager collectives between them)" % (
+                        step.segments.n_graphs, len(step.segments.items) - step.segments.n_graphs)
             except Exception as e:                          # never lose the measurement to a capture problem
                 print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
                 net.zero_grad(set_to_none=True)
@@ -405,7 +419,9 @@ def main():
                "ms_per_step_median_fenced": round(ms_median_fenced, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "dtype_note": dtype_note,
-               "config": {"workload": workload, "global_batch": a.B * world, "parallelism": f"dp{world}", "launch": mode,
+               "config": {"workload": workload, "global_batch": a.B * world,
+                          "parallelism": f"dp{world}" + (" (REHEARSAL: data-parallel code path on a 1-rank RCCL group)" if a.rehearse_dp else ""),
+                          "launch": mode,
                           "precision": getattr(a, "precision", "f32")},
                "final_loss": final_loss}
         out["roofline"], out["roofline_more"] = rl_main, rl_more

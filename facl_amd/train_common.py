@@ -177,7 +177,8 @@ class ContrastiveStep:
 class GraphedStep:
     """The whole training iteration (grouping -> forward -> losses -> backward -> Adam) captured once into a HIP
     graph and replayed: ~250 kernel launches per step collapse into one graph launch, so the step is no longer bound
-    by host launch latency.  Single-GPU only (collectives stay eager); the optimizer must keep its step counter on the device
+    by host launch latency.  Under data parallelism the capture is cut at every collective and the kernel segments between
+    them replay as graphs (collectives stay eager: facl_amd/dist.py: GraphSegments); the optimizer must keep its step counter on the device
     (facl_amd.optim.FusedAdam, or torch.optim.Adam(capturable=True, lr=<tensor>)).  Learning-rate changes between
     replays: FusedAdam's device-side lr is refreshed before every replay (`sync_lr`); with torch's capturable Adam only
     a TENSOR lr updated in place is seen by the graph."""
@@ -198,9 +199,30 @@ class GraphedStep:
         # would run ahead of the running-statistics updates: restore them afterwards.  NOTE: the 3 warm-up calls above
         # are REAL optimizer steps on `example_points` (they also settle the allocator and Adam's lazy state).
         saved = [(m, m.steps) for m in self._bn_modules()]
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = step.run(self.points, self.order)
+        if fdist.is_distributed():
+            # data parallel: the capture is cut at every collective (facl_amd/dist.py: GraphSegments) -- kernel segments
+            # replay as graphs, the collectives in between are ordinary eager RCCL calls on the same stream
+            self.graph = None
+            self.segments = rec = fdist.GraphSegments()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fdist.set_recorder(rec)
+                try:
+                    rec.begin()
+                    self.out = step.run(self.points, self.order)
+                    rec.end()
+                except BaseException:
+                    rec.abort()
+                    raise
+                finally:
+                    fdist.set_recorder(None)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+        else:
+            self.segments = None
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = step.run(self.points, self.order)
         for m, n in saved:
             m.steps = n
 
@@ -217,7 +239,10 @@ class GraphedStep:
         sync = getattr(self.step.optimizer, "sync_lr", None)
         if sync is not None:
             sync()                                       # a StepLR change made since the capture reaches k_adam_prep
-        self.graph.replay()
+        if self.segments is not None:
+            self.segments.replay()
+        else:
+            self.graph.replay()
         for m in self._bn_modules():                     # host-side num_batches_tracked (netR_FC.1 counts twice)
             m.count_batch()
         self.step.netR.netR_FC[1].count_batch()

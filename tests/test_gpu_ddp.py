@@ -194,3 +194,101 @@ def test_bench_gpus_flag_launches_ranks_or_fails_loudly():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["roofline"]["ms_per_launch"] > 0
+
+
+def _run_graphed_vs_eager(clip, G):
+    """Two identical models: one stepped eagerly, one through GraphedStep (segmented capture under data parallelism); three
+    optimizer steps each on the same clips; returns (eager losses, graph losses, max relative parameter difference,
+    number of graph segments, number of eager collectives between them)."""
+    from facl_amd import dist as fdist
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.optim import FusedAdam
+    from facl_amd.train_common import ContrastiveStep, GraphedStep
+    from oracle.weights import formula_state_dict
+    B, _, N, D = clip.shape
+    opt = _opt(D, B, N)
+    order = np.array([2, 0, 3, 1])
+    clips = [clip.cuda(), (clip * 0.9).cuda(), (clip * 1.1).cuda()]
+    nets, losses = [], []
+    for graphed in (False, True):
+        net = PointNet_Plus(opt, gost=G)
+        net.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(D).items()})
+        net = net.cuda().train()
+        net.bn_reduce_fn = fdist.make_bn_reduce_fn()
+        step = ContrastiveStep(net, FusedAdam(net.parameters(), lr=3e-4, betas=(0.5, 0.999), eps=1e-6), opt, G)
+        seg = None
+        if graphed:
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            step = GraphedStep(step, clips[0], G)        # 3 warm-up optimizer steps inside: restore the start state
+            seg = step.segments
+            net.load_state_dict(sd)
+            o = step.step.optimizer
+            o._step.zero_()
+            for st in o.state.values():
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+        ls = []
+        for c in clips:
+            loss, _, _ = step(c, epoch=0, order=order)
+            ls.append(float(loss.item()))
+        nets.append(net)
+        losses.append(ls)
+    worst = 0.0
+    for (k, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        worst = max(worst, float((a - b).norm() / a.norm().clamp_min(1e-12)))
+    return losses[0], losses[1], worst, seg.n_graphs, len(seg.items) - seg.n_graphs
+
+
+def _worker_graph(rank, world, port, q, backend):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from facl_amd import dist as fdist
+    import facl_amd.train_common as TC
+    torch.cuda.set_device(0)
+    if backend == "gloo":
+        os.environ["FACL_DIST_BACKEND"] = "gloo"
+        fdist.init_from_env()
+    else:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        fdist.is_distributed = lambda: True                      # force every collective on with a 1-rank RCCL group
+        TC.fdist.is_distributed = fdist.is_distributed
+    torch.manual_seed(3)
+    G, Bl, N, D = 4, 2, 512, 4
+    full = torch.rand(Bl * world, G, N, D) - 0.5
+    try:
+        res = _run_graphed_vs_eager(full[rank * Bl:(rank + 1) * Bl], G)
+    except BaseException:                                        # fail fast in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        os._exit(1)
+    q.put((rank,) + res)
+    if world > 1:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_segmented_graph_step_equals_eager_step_under_data_parallelism(backend, world):
+    """GraphedStep under data parallelism: the capture is cut at every collective (SyncBN all-reduces, embeddings all-gather
+    and its backward, the asynchronous tail bucket and the late bucket of the gradient average); kernel segments replay as
+    HIP graphs, the collectives run eagerly between them.  Three optimizer steps (FusedAdam) must give the eager step's
+    losses and parameters -- on 2 gloo ranks sharing the GPU, and on the real RCCL backend with a forced 1-rank group (every
+    RCCL call executes between graph replays, as it will with N > 1)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_graph, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] != "error", r[2]
+    for rank, l_eager, l_graph, worst, n_graphs, n_coll in res:
+        print(f"rank {rank}: eager {l_eager} graph {l_graph} worst param diff {worst:.2e}; {n_graphs} graphs, {n_coll} collectives")
+        assert n_coll >= 16 and n_graphs == n_coll + 1
+        for a, b in zip(l_eager, l_graph):
+            assert abs(a - b) <= 1e-5 * abs(a), (l_eager, l_graph)
+        assert worst < 1e-4

@@ -64,6 +64,7 @@ SIGNATURES = {
     "facl_gemm_wgrad_f16": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "facl_gemm_wgrad_pro": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_gemm_wgrad_pro_x3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    "facl_gemm_wgrad_h3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_gemm_rs_wgrad_slices": [c_l, c_i, c_i],
     "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_planes_bytes": [c_i, c_i, c_i],

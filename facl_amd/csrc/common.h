@@ -131,6 +131,7 @@ typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
 #define FACL_AMAX_SLOTS 64
 #define FACL_AMAX_STRIDE 32
 static_assert(FACL_AMAX_SLOTS * FACL_AMAX_STRIDE == FACL_AMAX_WORDS, "amax buffer layout");
+
 // two ALREADY SCALED values -> packed (h1, h2) fp16 pairs (element 0 in the low half)
 __device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, unsigned& lo) {
     const f32x2v v = {x0, x1};
@@ -142,4 +143,18 @@ __device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, u
 __device__ __forceinline__ f16x8h as_f16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
     const uint4 u = make_uint4(a, b, c, d);
     return __builtin_bit_cast(f16x8h, u);
+}
+
+// fp16x3 operand scale from the bits of max|x|: the power of two that puts the maximum in [2^13, 2^14) (fp16 overflows at
+// 2^16); sets `uns` = 1 / (scale * FACL_H3_SW).  max = 0 / denormal: the largest scale whose inverse stays normal.
+__device__ __forceinline__ float h3_dynamic_scale(const unsigned* amax, float& uns, float other_scale_log2) {
+    unsigned b = amax[(threadIdx.x & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE];    // one slot per lane (rows.hip: abs_max_slot)
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
+    const int e = (int)((__builtin_amdgcn_readfirstlane(b) >> 23) & 0xff);
+    int se = 267 - e;                                                   // biased exponent of 2^(13 - (e - 127))
+    se = se > 230 ? 230 : se;
+    const int ue = 254 - se - (int)other_scale_log2;                    // biased exponent of 2^-(se - 127) * 2^-other
+    uns = __uint_as_float((unsigned)ue << 23);
+    return __uint_as_float((unsigned)se << 23);
 }

@@ -42,6 +42,7 @@ struct GemmArgs {
     // (row block, column) max of sgn[j]*C and the FIRST row that attains it; 128x128 tiles only.  Null when unused.
     const float* sgn; float* smax; int* sarg;
     int prec;                          // 0: fp32 result (bf16x6 or fp32 MFMA), 1: fp16 inputs, one MFMA product, fp32 accumulate
+    const unsigned* amax;              // NP = 4 (fp16x3 weight gradient): bits of max|A| in hashed slots (common.h), A = dy
 };
 
 template <int LAY, int T>
@@ -547,15 +548,18 @@ __device__ __forceinline__ unsigned pk_f16(float x0, float x1) {
 }
 // PROI: relu(ps * x + pt) with the constants of the thread's OWN idx (an idx-contiguous operand whose prologue runs over
 // idx, not over k: the `a` operand of a weight gradient, a = relu(bn(y)) recomputed from the raw layer output)
+// NP = 4: fp16x3 (common.h): two fp16 planes of x * sc (sc = the operand's power-of-two scale)
 template <int T, int NP, bool PROI = false>
-__device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned (&pk)[12 * T], float ps = 1.f, float pt = 0.f) {
+__device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned (&pk)[12 * T], float ps = 1.f, float pt = 0.f,
+                                               float sc = 1.f) {
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float x0 = r[8 * i + 2 * j], x1 = r[8 * i + 2 * j + 1];
             if (PROI) { x0 = fmaxf(fmaf(ps, x0, pt), 0.f); x1 = fmaxf(fmaf(ps, x1, pt), 0.f); }
-            if (NP >= 2) split_pair(x0, x1, pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
+            if (NP == 4) split_pair_h(x0 * sc, x1 * sc, pk[12 * i + j], pk[12 * i + 4 + j]);
+            else if (NP >= 2) split_pair(x0, x1, pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
             else pk[12 * i + j] = pk_f16(x0, x1);
         }
 }
@@ -567,7 +571,7 @@ __device__ __forceinline__ void write_tile_ic8(unsigned short* __restrict__ S, c
     for (int i = 0; i < T; ++i) {
         unsigned short* d = S + il * SBROW + 8 * (kc + (4 / T) * i);
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < (NP == 4 ? 2 : NP); ++p)
             *reinterpret_cast<uint4*>(d + p * PLANE) =
                 make_uint4(pk[12 * i + 4 * p], pk[12 * i + 4 * p + 1], pk[12 * i + 4 * p + 2], pk[12 * i + 4 * p + 3]);
     }
@@ -614,14 +618,18 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
     // epilogue staging (floats): the fp16-input instantiation stages one 32-row tile at a time (gemm_epilogue_h) and keeps
     // only its single operand plane -> 35 KiB of LDS, three workgroups per CU
     constexpr int STG = NP == 1 ? 4 * 32 * (32 * TN + 4) : 4 * (32 * TM) * (32 * TN + 4);
-    constexpr int TILE_F = ((NP == 1 ? 1 : 3) * (APL + BPL) * 2 + 3) / 4;   // operand images in floats
+    constexpr int NPL = NP == 4 ? 2 : NP;                               // planes per operand in LDS (fp16x3: two fp16 planes)
+    static_assert(NP != 4 || (LA == IC && LB == IC), "fp16x3 is wired for the weight gradient (both operands idx-contiguous)");
+    constexpr int TILE_F = ((NP == 1 ? 1 : NP == 4 ? 2 : 3) * (APL + BPL) * 2 + 3) / 4;   // operand images in floats
     constexpr int SMEM = TILE_F > STG ? TILE_F : STG;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     unsigned short* const sA = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* const sB = sA + (NP == 1 ? 1 : 3) * APL;
+    unsigned short* const sB = sA + (NP == 1 ? 1 : NP == 4 ? 2 : 3) * APL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const TileId tile = xcd_tile();
+    float sca = 1.f, uns = 1.f;                                         // fp16x3: A = dy by its dynamic scale, B = activations by 2^4
+    if (NP == 4) sca = h3_dynamic_scale(g.amax, uns, 4.f);
     const int i0 = tile.y * BM, j0 = tile.x * BN;
     const int kbeg = tile.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
@@ -660,9 +668,9 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
     }
     auto split = [&](int k0) {
         if (LA == KC) split_tile_kc4<PRO, TM, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
-        else split_tile_ic8<TM, NP>(ra8, pka);
+        else split_tile_ic8<TM, NP>(ra8, pka, 1.f, 0.f, sca);
         if (LB == KC) split_tile_kc4<false, TN, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
-        else split_tile_ic8<TN, NP, PROB>(rb8, pkb, psb, ptb);
+        else split_tile_ic8<TN, NP, PROB>(rb8, pkb, psb, ptb, FACL_H3_SA);
     };
     auto write = [&]() {
         if (LA == KC) write_tile_kc4<TM, NP>(sA, pka, tid);
@@ -671,17 +679,28 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
         else write_tile_ic8<TN, NP>(sB, pkb, tid);
     };
     auto mfma_block = [&](int kk) {
-        bf16x8 af[TM][NP], bf[TN][NP];
+        bf16x8 af[TM][NPL], bf[TN][NPL];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NPL; ++p)
                 af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * APL + (32 * TM * wr + 32 * a + q) * SBROW + 16 * kk + 8 * h);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NPL; ++p)
                 bf[b][p] = *reinterpret_cast<const bf16x8*>(sB + p * BPL + (32 * TN * wc + 32 * b + q) * SBROW + 16 * kk + 8 * h);
+        if constexpr (NP == 4) {                                        // fp16x3: (lo,hi) (hi,lo) (hi,hi)
+            constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = MFMA_F16(__builtin_bit_cast(f16x8h, af[a][HA[t]]), __builtin_bit_cast(f16x8h, bf[b][HB[t]]), acc[a][b]);
+            return;
+        }
         if constexpr (NP == 1) {                                        // fp16 inputs: ONE product per multiply-add
 #pragma unroll
             for (int a = 0; a < TM; ++a)
@@ -716,6 +735,14 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
         __syncthreads();                                               // every wave has read this stage
         write();
         __syncthreads();
+    }
+    if constexpr (NP == 4) {                                            // exact rescale (a power of two)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] *= uns;
     }
     if constexpr (NP == 1) gemm_epilogue_h<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
     else gemm_epilogue<TM, TN>(g, acc, smem, i0, j0, wave, lane, tile.y, tile.z);
@@ -1041,6 +1068,33 @@ static int gemm_wgrad_pro_p(const float* dy, const float* y, int64_t M, int N, i
     dim3 grid((K + 127) / 128, (N + 127) / 128, nz);
     if (prec == 2) hipLaunchKernelGGL((k_gemm_sb<IC, IC, true, 2, 2, 2>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((k_gemm_sb<IC, IC, true, 2, 2, 3>), grid, dim3(256), 0, st, g);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    const long long n4 = (long long)N * K / 4;
+    const int rgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_sum_slices, dim3(rgrid), dim3(256), 0, st, slices, nz, n4, dW);
+    return facl_launch_status();
+}
+
+// fp16x3 weight gradient on the 128x128-tile kernel: dW (N,K) = dy^T f(y), f = relu(pscale*y + pshift) per column when pscale
+// is given, else identity; dy by the dynamic power-of-two scale read from `amax` (facl_rows_bwd_apply_amax), f(y) by 2^4
+// (|f(y)| < 4094).  FACL_E_CONFIG when the shape is not served (callers use the bf16x6 entries).
+extern "C" int facl_gemm_wgrad_h3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
+                                  const float* pshift, const uint32_t* amax, float* dW, float* slices, int nz, void* stream) {
+    if (!dy || !y || !amax || !dW || !slices || (pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
+    static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
+    if (use_f32) return FACL_E_CONFIG;
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk = (int)((M + nz - 1) / nz);
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    nz = (int)((M + kchunk - 1) / kchunk);
+    GemmArgs g{dy, N, y, ldy, slices, K, N, K, (int)M, nullptr, pscale, pshift, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr, 0, amax};
+    const long long big = (long long)((K + 127) / 128) * ((N + 127) / 128) * nz;
+    if (big < 256 || sbk_fits(g, nz)) return FACL_E_CONFIG;
+    dim3 grid((K + 127) / 128, (N + 127) / 128, nz);
+    if (pscale) hipLaunchKernelGGL((k_gemm_sb<IC, IC, true, 2, 2, 4>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_sb<IC, IC, false, 2, 2, 4>), grid, dim3(256), 0, st, g);
     int rc = facl_launch_status();
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;

@@ -57,19 +57,6 @@ struct RsArgs {
                                                   // chosen per launch (gradients); null: the fixed activation scale 2^4
 };
 
-// fp16x3 operand scale from the bits of max|x|: the power of two that puts the maximum in [2^13, 2^14) (fp16 overflows at
-// 2^16); sets `uns` = 1 / (scale * FACL_H3_SW).  max = 0 / denormal: the largest scale whose inverse stays normal.
-__device__ __forceinline__ float h3_dynamic_scale(const unsigned* amax, float& uns, float other_scale_log2) {
-    unsigned b = amax[(threadIdx.x & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE];    // one slot per lane (rows.hip: abs_max_slot)
-#pragma unroll
-    for (int o = 32; o; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
-    const int e = (int)((__builtin_amdgcn_readfirstlane(b) >> 23) & 0xff);
-    int se = 267 - e;                                                   // biased exponent of 2^(13 - (e - 127))
-    se = se > 230 ? 230 : se;
-    const int ue = 254 - se - (int)other_scale_log2;                    // biased exponent of 2^-(se - 127) * 2^-other
-    uns = __uint_as_float((unsigned)ue << 23);
-    return __uint_as_float((unsigned)se << 23);
-}
 
 
 // ---- weights -> fragment-ordered bf16 planes -------------------------------------------------------------------------

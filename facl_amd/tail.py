@@ -91,8 +91,9 @@ def gemm_dgrad(dy, W, prec=None):
     return da
 
 
-def gemm_wgrad(dy, a, prec=None):
-    """dW = dy^T a, contraction over the rows split into slices (deterministic slice-order sum)."""
+def gemm_wgrad(dy, a, prec=None, amax=None):
+    """dW = dy^T a, contraction over the rows split into slices (deterministic slice-order sum).  `amax` (the device-side
+    max|dy| buffer of facl_rows_bwd_apply_amax): fp16x3 arithmetic where the 128x128-tile kernel serves the shape."""
     lib = _lib.load_library()
     M, N = dy.shape
     K = a.shape[1]
@@ -101,6 +102,13 @@ def gemm_wgrad(dy, a, prec=None):
     dW = _lib.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = _lib.empty(nz * N * K, dtype=torch.float32, device=dy.device)
     prec = current_precision() if prec is None else prec
+    if amax is not None and prec == "f32":
+        with _lib.timed("facl_gemm_wgrad %dx%dx%d h3" % (M, N, K)):
+            rc = lib.facl_gemm_wgrad_h3(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), None, None, _lib.ptr(amax), _lib.ptr(dW),
+                                        _lib.ptr(slices), nz, _lib.stream())
+        if rc != -4:
+            _lib.check(rc, "facl_gemm_wgrad_h3")
+            return dW
     with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
         _lib.check(_fn(lib, "facl_gemm_wgrad", prec)(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), _lib.ptr(dW), _lib.ptr(slices), nz,
                                        _lib.stream()), "facl_gemm_wgrad")
@@ -584,6 +592,13 @@ def _wgrad_pro(dy, y, bnc, prec, amax=None):
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     nz = max(1, min((M + 255) // 256, 512 // tiles))
     slices = _lib.empty(nz * N * K, dtype=torch.float32, device=dy.device)
+    if amax is not None and prec == "f32":                              # fp16x3 on the LDS-staged kernel (the narrower layers)
+        with _lib.timed("facl_gemm_wgrad %dx%dx%d h3" % (M, N, K)):
+            rc = lib.facl_gemm_wgrad_h3(_lib.ptr(dy), _lib.ptr(y), M, N, K, y.stride(0), _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
+                                        _lib.ptr(amax), _lib.ptr(dW), _lib.ptr(slices), nz, _lib.stream())
+        if rc != -4:
+            _lib.check(rc, "facl_gemm_wgrad_h3")
+            return dW
     fn = lib.facl_gemm_wgrad_pro_x3 if prec == "x3" else lib.facl_gemm_wgrad_pro
     with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M, N, K, _LABEL[prec])):
         rc = fn(_lib.ptr(dy), _lib.ptr(y), M, N, K, y.stride(0), _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(dW),
@@ -695,7 +710,7 @@ class _Net3DV3(torch.autograd.Function):
                 dW = _wgrad_pro(dy, yin, bnc_in, bp, am(li))
                 da, sums = _rs_dgrad(dy, W, bp, bpl[1], yin, bnc_in, ws, am(li))
             else:                                                       # first layer: input = pooled | centres
-                dWh = gemm_wgrad(dy, pooled, prec=bp)
+                dWh = gemm_wgrad(dy, pooled, prec=bp, amax=am(li))
                 dWc = _lib.empty((C, 3), **f64)
                 _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(centers), P, C, _lib.ptr(dWc), _lib.ptr(ws), st),
                            "facl_rows_center_wgrad")

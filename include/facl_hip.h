@@ -276,6 +276,11 @@ int facl_gemm_wgrad_pro(const float* dy, const float* y, int64_t M, int N, int K
                         const float* pshift, float* dW, float* slices, int nz, void* stream);
 int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
                            const float* pshift, float* dW, float* slices, int nz, void* stream);
+/* the same weight gradient in fp16x3 (see `half` above): dy by the dynamic scale read from `amax` (the FACL_AMAX_WORDS buffer of
+ * facl_rows_bwd_apply_amax), the activation operand by 2^4; pscale / pshift null: `y` IS the activation.  FACL_E_CONFIG when
+ * the shape is not served by the 128x128-tile kernel (callers use the bf16x6 entries). */
+int facl_gemm_wgrad_h3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
+                       const float* pshift, const uint32_t* amax, float* dW, float* slices, int nz, void* stream);
 /* Weight gradient of the widest layer on the register-streamed kernel (csrc/gemm_rs.hip: k_wgrad_rs): dW (N,K) =
  * dy^T f(y), f = relu(pscale*y + pshift) when pscale is given (else identity).  facl_gemm_rs_wgrad_slices returns the number
  * of row slices the call will use (scratch = that many x N x K floats), or 0 when the shape is not served (N % 512, K % 128,

@@ -28,6 +28,18 @@ def test_library_builds_and_exports_header_symbols():
     assert lib.facl_version() >> 16 == 1
 
 
+def test_header_constants_match_the_python_binding():
+    """Buffer-size constants the ABI shares with callers (include/facl_hip.h) vs facl_amd/_lib.py."""
+    from facl_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "facl_hip.h")).read()
+    m = re.search(r"#define\s+FACL_AMAX_WORDS\s+(\d+)", txt)
+    assert m and int(m.group(1)) == _lib.AMAX_WORDS
+    common = open(os.path.join(ROOT, "facl_amd", "csrc", "common.h")).read()
+    slots = int(re.search(r"#define\s+FACL_AMAX_SLOTS\s+(\d+)", common).group(1))
+    stride = int(re.search(r"#define\s+FACL_AMAX_STRIDE\s+(\d+)", common).group(1))
+    assert slots * stride == _lib.AMAX_WORDS and stride * 4 == 128           # one 128-byte line per slot
+
+
 def test_no_cpu_fallback():
     """Product ops refuse CPU tensors instead of silently computing somewhere else."""
     import torch

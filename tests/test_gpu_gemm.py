@@ -441,6 +441,20 @@ def test_gemm_rs_backward_fp16x3_dynamic_scale(M, N, K, mag):
             errs[half] = rel_err(dW.cpu().numpy(), refw.cpu().numpy())
         print(f"wgrad fp16x3 {errs[1]:.2e}   bf16x6 {errs[0]:.2e}")
         assert errs[1] < 3e-6 and errs[1] < 2.0 * errs[0]
+    # ---- the narrower layers' weight gradient on the LDS-staged kernel (facl_gemm_wgrad_h3), with and without the prologue
+    for K3, pro in ((256, True), (256, False)):
+        y3 = torch.randn(M, K3, device=DEV, generator=g) * 3.0
+        ps, pt = torch.rand(K3, device=DEV, generator=g) + 0.5, torch.randn(K3, device=DEV, generator=g) * 0.3
+        a64 = torch.relu(y3.double() * ps.double() + pt.double()) if pro else y3.double()
+        refw = dy.double().t() @ a64
+        nz = 256 // ((N // 128) * (K3 // 128)) + 1                     # at least one resident round of 128x128 workgroups
+        dW, sl = _lib.empty(N, K3, device=DEV), _lib.empty(nz * N * K3, device=DEV)
+        rc = lib.facl_gemm_wgrad_h3(p(dy), p(y3), M, N, K3, K3, p(ps) if pro else None, p(pt) if pro else None, p(amax), p(dW), p(sl),
+                                    nz, _lib.stream())
+        _lib.check(rc, "wgrad_h3")
+        e = rel_err(dW.cpu().numpy(), refw.cpu().numpy())
+        print(f"wgrad (staged kernel) fp16x3 {e:.2e}  pro={pro}")
+        assert e < 3e-6
 
 
 def test_segmax_bwd_apply_amax_publishes_the_exact_maximum():
@@ -462,3 +476,33 @@ def test_segmax_bwd_apply_amax_publishes_the_exact_maximum():
     _lib.check(lib.facl_segmax_bwd_apply(p(dxpre), p(xpre), p(y), p(arg), Mc, S, C, p(bnc), p(kk), p(dy2), _lib.stream()), "segmax_apply")
     assert torch.equal(dy, dy2)
     assert float(amax.view(torch.float32).max()) == float(dy.abs().max())
+
+
+def test_fp16x3_forward_range_contract_fails_loudly():
+    """fp16x3's range contract (include/facl_hip.h): forward activations below 4094 and weights below 255 in magnitude.
+    Inside it the result is fp32-grade up to the edge; beyond it an fp16 piece overflows and the affected outputs are
+    NaN / inf -- never a finite wrong number -- while half = 0 (bf16x6) has no such limit."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    p = _lib.ptr
+    M, K, N = 2048, 64, 256
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.zeros(N, device=DEV)
+    a[5, 7] = 4000.0                                                   # inside: 4000 * 2^4 < 65504
+    W[3, 9] = 250.0
+    def run(half):
+        planes = _rs_planes(lib, W, False, None, half)
+        y = _lib.empty(M, N, device=DEV)
+        _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), half, N, p(b), None, None, None, p(y), None, None, None, None,
+                                        p(_ws()), _lib.stream()), "rs_fwd")
+        return y
+    ref = a.double() @ W.double().t()
+    assert rel_err(run(1).cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    a[5, 7] = 5000.0                                                   # outside: 5000 * 2^4 overflows fp16
+    y1, y0 = run(1), run(0)
+    ref = a.double() @ W.double().t()
+    assert not torch.isfinite(y1[5]).all()                             # loud on the affected row ...
+    assert torch.isfinite(y1[:5]).all() and torch.isfinite(y1[6:]).all()   # ... and only there
+    assert rel_err(y0.cpu().numpy(), ref.cpu().numpy()) < 2e-6         # bf16x6: no range limit

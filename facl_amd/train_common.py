@@ -64,6 +64,9 @@ def build_parser(default_branch):
     p.add_argument('--precision', type=str, default='f32', choices=('f32', 'x3b', 'x3'),
                    help='NEW: arithmetic of the dense contractions (facl_amd.tail.precision): f32 = fp32-grade (default); '
                         'x3b = three bf16 products in the backward GEMMs only (features / loss unchanged); x3 = everywhere')
+    p.add_argument('--graph', type=int, default=1,
+                   help='NEW: 1 = replay the iteration as HIP graph(s) (train_common.GraphedStep; the eager loop is host-bound at '
+                        'this step time); needs the default loss (swa_if = cld_if = 0).  0 = eager launches')
     p.add_argument('--fps_reorder', type=int, default=0,
                    help='NEW: 1 = FPS-reorder every view on the GPU before grouping (cn3D_data_set.py:665-672; the '
                         'reference assumes FPS-ordered clouds but its live loader never calls it)')
@@ -183,11 +186,20 @@ class GraphedStep:
     replays: FusedAdam's device-side lr is refreshed before every replay (`sync_lr`); with torch's capturable Adam only
     a TENSOR lr updated in place is seen by the graph."""
 
-    def __init__(self, step, example_points, G):
+    def __init__(self, step, example_points, G, restore=False):
+        """`restore`: put parameters, BatchNorm buffers and optimizer state back to what they were before the three
+        warm-up steps, so that a training run continues exactly where an eager run would be."""
         self.step, self.G = step, G
         dev = example_points.device
         self.points = example_points.clone()
         self.order = torch.arange(G, dtype=torch.long, device=dev)
+        snap = None
+        if restore:
+            snap = ({k: v.detach().clone() for k, v in step.netR.state_dict().items()},
+                    step.optimizer.state_dict() if hasattr(step.optimizer, "_step") else None)
+            if snap[1] is not None:                       # FusedAdam.state_dict() shares its moment tensors: deep copy
+                snap = (snap[0], {"state": {i: {k: v.clone() for k, v in st.items()} for i, st in snap[1]["state"].items()},
+                                  "param_groups": snap[1]["param_groups"]})
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                       # warm-up on a side stream (allocator + lazy inits)
@@ -225,6 +237,15 @@ class GraphedStep:
                 self.out = step.run(self.points, self.order)
         for m, n in saved:
             m.steps = n
+        if snap is not None:
+            with torch.no_grad():                        # in place: the graph holds the addresses of these tensors
+                cur = step.netR.state_dict()
+                for k, v in snap[0].items():
+                    cur[k].copy_(v)
+            for m in self._bn_modules():
+                m.steps = int(m.num_batches_tracked) if hasattr(m, "num_batches_tracked") else m.steps
+            if snap[1] is not None:
+                step.optimizer.load_state_dict(snap[1])
 
     def _bn_modules(self):
         return [m for m in self.step.netR.modules() if hasattr(m, "count_batch")]
@@ -283,6 +304,7 @@ def run(default_branch, ckpt_pattern, args=None):
     gen = torch.Generator(device=device)
     gen.manual_seed(1000 + rank)
 
+    run_step = step
     for epoch in range(0, opt.nepoch):
         netR.train()
         for g in optimizer.param_groups:
@@ -293,7 +315,14 @@ def run(default_branch, ckpt_pattern, args=None):
                 raise RuntimeError("only --synthetic 1 is supported: the NTU dataset pipeline "
                                    "(cn3D_data_set.py) is outside this repository's scope")
             out_points = synthetic_batch(opt.batchSize, num_crop, opt.SAMPLE_NUM, opt.INPUT_FEATURE_NUM, device, gen)
-            loss, _, _ = step(out_points, epoch)
+            if run_step is step and opt.graph and not (opt.swa_if or opt.cld_if):
+                try:                                     # capture on the first batch; state restored: same trajectory as eager
+                    run_step = GraphedStep(step, out_points, num_crop, restore=True)
+                except Exception as e:                   # keep training on eager launches
+                    print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e))
+                    opt.graph = 0
+                    netR.zero_grad(set_to_none=True)
+            loss, _, _ = run_step(out_points, epoch)
             torch.cuda.synchronize()
             loss_sigma += loss.item()
         clips = opt.batchSize * opt.steps_per_epoch * world / (time.time() - t0)

@@ -53,6 +53,24 @@ def test_train_entry_checkpoint_then_extract(tmp_path):
     assert err.max() < 1e-4, err
 
 
+def test_train_entry_graph_mode_follows_the_eager_trajectory(tmp_path):
+    """--graph 1 (default): the entry captures the iteration on its first batch (three warm-up steps, state restored) and
+    replays it; parameters, BatchNorm buffers and counters after 2 epochs x 3 steps equal the --graph 0 run's."""
+    from facl_amd import cn3d_train_motion_GL as train
+    args = ["--batchSize", "4", "--nepoch", "2", "--steps_per_epoch", "3", "--num_crop", "4", "--SAMPLE_NUM", "512",
+            "--INPUT_FEATURE_NUM", "4"]
+    sds = []
+    for gflag in ("1", "0"):
+        net = train.main(args + ["--graph", gflag, "--save_root_dir", str(tmp_path / ("ck" + gflag))])
+        sds.append({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    for k, v in sds[0].items():
+        if v.is_floating_point():
+            assert torch.allclose(v, sds[1][k], rtol=1e-5, atol=1e-7), k
+        else:
+            assert torch.equal(v, sds[1][k]), k
+    assert int(sds[0]["net3DV_1.1.num_batches_tracked"]) == 6
+
+
 def test_graph_replay_equals_eager():
     from facl_amd.cn3d_model_conbag import PointNet_Plus
     from facl_amd.train_common import ContrastiveStep, GraphedStep

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2(const float* __restrict__ x,
 // pre-split planes in LDS (24 KiB), the lane computes layer 1 for its two positions on exactly the 32 channels its
 // k-slots need (block kk, half h, slot j <-> channel 16kk + 8h + j) and splits them in registers.  96 MFMAs per unit
 // instead of 128 four-times-slower ones: the kernel becomes bound by its 16 KiB/unit store stream.
-template <int D>
+template <int D, bool H3>
 __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__ x, int nunits,
                                                        const float* __restrict__ l1tab_g, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, float* __restrict__ y2f,
@@ -205,16 +205,28 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
         const float* wrow = W2 + (32 * rt + (ln & 31)) * 64 + 16 * kk + 8 * (ln >> 5);
         const float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 4);
         unsigned hi[4], mi[4], lo[4];
-        split_pair(w0.x, w0.y, hi[0], mi[0], lo[0]);
-        split_pair(w0.z, w0.w, hi[1], mi[1], lo[1]);
-        split_pair(w1.x, w1.y, hi[2], mi[2], lo[2]);
-        split_pair(w1.z, w1.w, hi[3], mi[3], lo[3]);
+        if (H3) {                                            // fp16x3 (common.h): two fp16 planes of w * 2^8 in slots 0 and 1
+            split_pair_h(w0.x * FACL_H3_SW, w0.y * FACL_H3_SW, hi[0], mi[0]);
+            split_pair_h(w0.z * FACL_H3_SW, w0.w * FACL_H3_SW, hi[1], mi[1]);
+            split_pair_h(w1.x * FACL_H3_SW, w1.y * FACL_H3_SW, hi[2], mi[2]);
+            split_pair_h(w1.z * FACL_H3_SW, w1.w * FACL_H3_SW, hi[3], mi[3]);
+            lo[0] = lo[1] = lo[2] = lo[3] = 0u;
+        } else {
+            split_pair(w0.x, w0.y, hi[0], mi[0], lo[0]);
+            split_pair(w0.z, w0.w, hi[1], mi[1], lo[1]);
+            split_pair(w1.x, w1.y, hi[2], mi[2], lo[2]);
+            split_pair(w1.z, w1.w, hi[3], mi[3], lo[3]);
+        }
         uint4* d = w2p + ((rt * 4 + kk) * 3) * 64 + ln;
         d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
         d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
-    if (threadIdx.x < 128) l1tab[threadIdx.x] = reinterpret_cast<const float4*>(l1tab_g)[threadIdx.x];
+    if (threadIdx.x < 128) {
+        float4 t = reinterpret_cast<const float4*>(l1tab_g)[threadIdx.x];
+        if (H3) { t.x *= FACL_H3_SA; t.y *= FACL_H3_SA; t.z *= FACL_H3_SA; t.w *= FACL_H3_SA; }   // relu(16 w.x + 16 b) = 16 relu(w.x + b): exact
+        l1tab[threadIdx.x] = t;
+    }
     if (threadIdx.x < 16) b2s[threadIdx.x] = reinterpret_cast<const float4*>(b2)[threadIdx.x];
     __syncthreads();
 
@@ -271,8 +283,13 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 unsigned hi[4], mi[4], lo[4];
+                if (H3) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) split_pair(a1[ct][2 * t], a1[ct][2 * t + 1], hi[t], mi[t], lo[t]);
+                    for (int t = 0; t < 4; ++t) { split_pair_h(a1[ct][2 * t], a1[ct][2 * t + 1], hi[t], mi[t]); lo[t] = 0u; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) split_pair(a1[ct][2 * t], a1[ct][2 * t + 1], hi[t], mi[t], lo[t]);
+                }
                 ap[ct][kk][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
                 ap[ct][kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
                 ap[ct][kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
@@ -283,7 +300,8 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 bb = b2s[8 * rt + 2 * r4 + h];
+                float4 bb = b2s[8 * rt + 2 * r4 + h];
+                if (H3) { bb.x *= 4096.f; bb.y *= 4096.f; bb.z *= 4096.f; bb.w *= 4096.f; }   // the accumulator runs at (a 2^4)(w 2^8)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     acc[rt][ct][4 * r4 + 0] = bb.x; acc[rt][ct][4 * r4 + 1] = bb.y;
@@ -297,13 +315,32 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wf[rt][pl] = __builtin_bit_cast(bf16x8, w2p[((rt * 4 + kk) * 3 + pl) * 64 + lane]);
+                for (int pl = 0; pl < (H3 ? 2 : 3); ++pl) wf[rt][pl] = __builtin_bit_cast(bf16x8, w2p[((rt * 4 + kk) * 3 + pl) * 64 + lane]);
+            if (H3) {
+                constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = MFMA_BF16(wf[rt][PA[t]], ap[ct][kk][PB[t]], acc[rt][ct]);
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[rt][ct] = MFMA_F16(__builtin_bit_cast(f16x8h, wf[rt][HA[t]]), __builtin_bit_cast(f16x8h, ap[ct][kk][HB[t]]), acc[rt][ct]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = MFMA_BF16(wf[rt][PA[t]], ap[ct][kk][PB[t]], acc[rt][ct]);
+            }
+        }
+        if (H3) {                                            // exact rescale (2^-12)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rt][ct][r] *= FACL_H3_UNSCALE;
         }
         float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
 #pragma unroll
@@ -744,8 +781,15 @@ extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* 
         if (D == 4) hipLaunchKernelGGL((k_sa_fwd2<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
         else hipLaunchKernelGGL((k_sa_fwd2<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
     } else {
-        if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
-        else hipLaunchKernelGGL((k_sa_fwd2_sb<3>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+        // fp16x3 (two fp16 planes, three products: csrc/common.h) unless FACL_FWD_H3=0 selects bf16x6 (A/B)
+        static const int h3 = getenv("FACL_FWD_H3") ? atoi(getenv("FACL_FWD_H3")) : 1;
+        if (h3) {
+            if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4, true>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+            else hipLaunchKernelGGL((k_sa_fwd2_sb<3, true>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+        } else {
+            if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4, false>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+            else hipLaunchKernelGGL((k_sa_fwd2_sb<3, false>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+        }
     }
     int rc = facl_launch_status();
     if (rc || !sums2) return rc;

@@ -149,7 +149,7 @@ def kernel_models(a, K=64):
         "facl_fps": dict(kernel="k_fps", flops=M * S * a.N * 9.0, pipe="valu", bytes=M * (a.N * D * 4.0 + S * 4.0)),
         "facl_group": dict(kernel="k_group", flops=M * S * a.N * 8.0, pipe="valu",
                            bytes=M * (a.N * D * 4.0 + S * K * D * 4.0 + S * 12.0)),
-        "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "bf16x6",
+        "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "fp16x3" if fwd_h3 else "bf16x6",
                              flops=nunits * 2.0 * 64 * 64 * 64, bytes=nunits * (64 * D * 4.0 + y2)),
         "facl_sa_fwd3": dict(kernel="k_sa_fwd3_sb<fp16>" if a.config == "dense" else ("k_sa_fwd3" if sa_f32 else
                                     "k_sa_fwd3_sb<x3>" if getattr(a, "precision", "f32") == "x3" else "k_sa_fwd3_sb"),

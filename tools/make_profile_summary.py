@@ -20,6 +20,8 @@ def main():
     names = ["bench_line", "bench_appearance", "bench_dense", "bench_2rank_gloo_rehearsal"]
     if os.path.exists(os.path.join(go, f"{tag}_bench_fps.json")):
         names.insert(1, "bench_fps")
+    if os.path.exists(os.path.join(go, f"{tag}_bench_rehearse_dp.json")):
+        names.append("bench_rehearse_dp")
     optin = [n for n in ("bench_optin_x3b", "bench_optin_x3") if os.path.exists(os.path.join(go, f"{tag}_{n}.json"))]
     names += optin
     for n in names:
@@ -79,6 +81,11 @@ def main():
         tbl += "| `%s` | %.4f | %s | %s | %.1f %s | %.0f | %.3f | %.1f | %.3f | %s |\n" % (
             r["kernel"], r["ms_per_launch"], r.get("pipe", "-"), r["bound"], r["achieved"], r["unit"], r["peak"], r["frac"],
             r.get("algorithmic_tflops", 0.0), r["hbm_frac"], tr)
+    dp_row = ""
+    if "bench_rehearse_dp" in L:
+        dp_row = (f'| `python bench.py --rehearse-dp 1` (the DATA-PARALLEL code path on one GPU: every collective of the N > 1 step executes '
+                  f'on a 1-rank RCCL group, the step replays as graph segments cut at the collectives; not a scaling number) | '
+                  f'{L["bench_rehearse_dp"]["ms_per_step"]} | {L["bench_rehearse_dp"]["value"]} | `{tag}_bench_rehearse_dp.json` |\n')
     optin_rows = "".join(
         f'| `python bench.py --precision {n.split("_")[-1]}` (OPT-IN arithmetic, not the headline: DESIGN 3.0) | {L[n]["ms_per_step"]} | '
         f'{L[n]["value"]} | `{tag}_{n}.json` |\n' for n in optin)
@@ -90,7 +97,8 @@ Command (on the GPU box, from /tmp with TMPDIR=/tmp):
 `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_{tag} -o r -- python3 bench.py`
 Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-step figures below divide by {steps} executed steps).
 
-## bench.py lines of this build, un-profiled, same box (`profiles/{tag}_bench_*.json`)
+## bench.py lines of this build, un-profiled (`profiles/{tag}_bench_*.json`; re-run AFTER the PMC tables below were regenerated so that
+## their `traffic` / `mfma_util_pmc` fields come from this build -- possibly on another box of the pool than the profiled run: box to box the headline varies by ~7 %)
 
 | command | ms/step | clips/s | file |
 |---|---|---|---|
@@ -98,7 +106,7 @@ Raw per-kernel table: `profiles/{tag}_default_cmd_kernel_stats.csv` (the per-ste
 {fps_row}| `python bench.py --config appearance --D 4` (configs[2]) | {L["bench_appearance"]["ms_per_step"]} | {L["bench_appearance"]["value"]} | `{tag}_bench_appearance.json` |
 | `python bench.py --config dense` (configs[4]: B=8 T=32 N=4096, 3-level SA, fp16-input MFMA) | {L["bench_dense"]["ms_per_step"]} | {L["bench_dense"]["value"]} | `{tag}_bench_dense.json` (own metric string; cpu_baseline {L["bench_dense"].get("cpu_baseline", {}).get("value", "-")} clips/s) |
 | `FACL_DIST_BACKEND=gloo python bench.py --gpus 2 --B 16` (2 ranks REHEARSED on one GPU with CPU collectives: launcher, sharded step, SyncBN, all-gather; not a scaling number) | {L["bench_2rank_gloo_rehearsal"]["ms_per_step"]} | {L["bench_2rank_gloo_rehearsal"]["value"]} | `{tag}_bench_2rank_gloo_rehearsal.json` |
-{optin_rows}
+{dp_row}{optin_rows}
 ## Roofline section of `{tag}_bench_line.json` (every heavy entry, timed inside the step)
 
 {tbl}

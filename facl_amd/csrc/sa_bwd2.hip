@@ -48,7 +48,7 @@ template <int D>
 __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
     const float* __restrict__ dz2f, const float* __restrict__ y2f, const float* __restrict__ x, int nunits,
     const float* __restrict__ bw2 /* (4,64): scale2, A, B, mean2 */, const float* __restrict__ W2,
-    const float* __restrict__ l1tab_g, double* __restrict__ part) {
+    const float* __restrict__ l1tab_g, double* __restrict__ part, int rev) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     uint4* w2p = reinterpret_cast<uint4*>(lds4);            // [(ct1*4 + kk)*3 + plane][lane]: 1536 uint4 = 24 KiB
     float4* tab = lds4 + 1536;                              // 4 x 16 float4
@@ -110,7 +110,10 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
         for (int d = 0; d < 5; ++d) r1[a][d] = 0.f;
     constexpr int PA[6] = FACL_SB_PA, PB[6] = FACL_SB_PB;
 
-    for (int u = wave_g; u < nunits; u += nwaves) {
+    // rev: walk the units from the LAST one down.  The pass before this one (k_sa_bwd1) wrote dz2 and read y2 front to back, so
+    // the ends of both arrays are what the memory-side cache (256 MB) still holds when this kernel starts.
+    for (int uu = wave_g; uu < nunits; uu += nwaves) {
+        const int u = rev ? nunits - 1 - uu : uu;
         {   // x of the unit -> LDS (one float4 per position)
             const size_t p = (size_t)u * 64 + lane;
             float4 xv;
@@ -258,8 +261,9 @@ int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, 
         if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
         attr_done = true;
     }
-    if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4>), dim3(grid), dim3(64 * B2S_WAVES), lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws);
-    else hipLaunchKernelGGL((k_sa_bwd2_sb<3>), dim3(grid), dim3(64 * B2S_WAVES), lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws);
+    static const int rev = getenv("FACL_BWD2_REV") ? atoi(getenv("FACL_BWD2_REV")) : 1;
+    if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4>), dim3(grid), dim3(64 * B2S_WAVES), lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+    else hipLaunchKernelGGL((k_sa_bwd2_sb<3>), dim3(grid), dim3(64 * B2S_WAVES), lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
     return facl_launch_status();
 }
 

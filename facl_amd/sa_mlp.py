@@ -221,19 +221,20 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     if reduce_fn is not None:
         sums1 = reduce_fn(sums1.clone())
 
-    # ---- layer-3 weight gradient ingredients: sparse gather, Gram, sum a2
-    out3 = _lib.empty(256 * 64 + 64 * 64 + 64, **f64)
-    with _lib.timed("facl_sa_bwd_w3"):
-        _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
-                   "facl_sa_bwd_w3")
-
-    # ---- pass 2: dy2, da1, dz1, dW2, R1
+    # ---- pass 2: dy2, da1, dz1, dW2, R1 -- launched right behind pass 1 and walking the units backwards: the ends of dz2 / y2
+    # that pass 1 touched last are still in the memory-side cache (FACL_BWD2_REV=0: front to back)
     bw2 = _lib.empty((4, 64), **f32)
     _lib.check(lib.facl_sa_bwd_consts2(ptr(sums1), ptr(bnc2), P, ptr(bw2), st), "facl_sa_bwd_consts2")
     out2 = _lib.empty(64 * 64 + 8 * 64, **f64)
     with _lib.timed("facl_sa_bwd2"):
         _lib.check(lib.facl_sa_bwd2(ptr(dz2f), ptr(ctx["y2f"]), ptr(x_rows), nunits, D, ptr(bw2), ptr(W2), ptr(ctx["l1tab"]),
                                     ptr(out2), ptr(ws), st), "facl_sa_bwd2")
+    # ---- layer-3 weight gradient ingredients: sparse gather, Gram, sum a2
+    out3 = _lib.empty(256 * 64 + 64 * 64 + 64, **f64)
+    with _lib.timed("facl_sa_bwd_w3"):
+        _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
+                   "facl_sa_bwd_w3")
+
     R1_g = out2[4096:]
     if reduce_fn is not None:
         R1_g = reduce_fn(R1_g.clone())

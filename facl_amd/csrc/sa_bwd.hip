@@ -98,15 +98,52 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
                                                  const float* __restrict__ coef, const unsigned char* __restrict__ arg,
                                                  float* __restrict__ dz2f, double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float4* g3f = lds4;                                   // [rt'][rt][r4][lane]  (1024 float4)
+    float g3scale, g3uns;
     float* w3n = reinterpret_cast<float*>(lds4 + 1024);   // W3 natural (256,64)
     float4* tab = lds4 + 1024 + 4096;                     // mean2, invstd2, scale2, shift2, h3: 5 x 16 float4
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave & 3;
     float* T = reinterpret_cast<float*>(tab + 80) + pair * (64 * TP);
-    for (int i = threadIdx.x; i < 1024; i += 512) {
-        const int ln = i & 63, r4 = (i >> 6) & 3, rt = (i >> 8) & 1, rto = i >> 9;
-        g3f[i] = *reinterpret_cast<const float4*>(G3 + (32 * rto + (ln & 31)) * 64 + 32 * rt + 8 * r4 + 4 * (ln >> 5));
+    // G3 = W3^T diag(g) W3 carries the gradient's magnitude: its fp16x3 planes (common.h) use the power of two that puts
+    // max|G3| in [2^13, 2^14) -- found by the workgroup itself, no host round trip.  Fragment order of the A operand of
+    // v_mfma_f32_32x32x16_f16: entry ((ro*4 + kb)*2 + plane)*64 + lane holds, for lane (row j = 32 ro + q, half h), the 8
+    // k-slots t of k-block kb = 2 rt + m: channel 32 rt + 16 m + (t & 3) + 8 (t >> 2) + 4 h -- exactly the channels the lane's
+    // y2 fragment registers 8m .. 8m+7 hold (rowmap), so the activations need no shuffle.
+    uint4* g3p = reinterpret_cast<uint4*>(lds4);          // 2 x 4 x 2 x 64 uint4 = 16 KiB (in place of the fp32 fragments)
+    float* red = reinterpret_cast<float*>(lds4 + 1024 + 4096 + 80) ;   // the T tiles are idle until the first round: 8 floats
+    {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < 1024; i += 512) {
+            const float4 v = reinterpret_cast<const float4*>(G3)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+        __syncthreads();
+        // scale 2^(13 - floor(log2 m)) (m = 0, denormal or huge: clamped so that scale and its inverse stay normal)
+        int se = 267 - (int)((__float_as_uint(m) >> 23) & 0xff);
+        se = se > 230 ? 230 : se;
+        se = __builtin_amdgcn_readfirstlane(se);                       // wave-uniform: keep the two factors in scalar registers
+        g3scale = __uint_as_float((unsigned)se << 23);
+        g3uns = __uint_as_float((unsigned)(254 - se - 4) << 23);      // 1 / (scale * 2^4): the activations ride at 2^4
+    }
+    for (int i = threadIdx.x; i < 512; i += 512) {
+        const int ln = i & 63, kb = (i >> 6) & 3, ro = i >> 8;
+        const int rt = kb >> 1, mm = kb & 1;
+        const float* row = G3 + (32 * ro + (ln & 31)) * 64 + 32 * rt + 16 * mm + 4 * (ln >> 5);
+        const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 8);
+        unsigned hi[4], lo[4];
+        split_pair_h(v0.x * g3scale, v0.y * g3scale, hi[0], lo[0]);
+        split_pair_h(v0.z * g3scale, v0.w * g3scale, hi[1], lo[1]);
+        split_pair_h(v1.x * g3scale, v1.y * g3scale, hi[2], lo[2]);
+        split_pair_h(v1.z * g3scale, v1.w * g3scale, hi[3], lo[3]);
+        g3p[((ro * 4 + kb) * 2) * 64 + ln] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        g3p[((ro * 4 + kb) * 2 + 1) * 64 + ln] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
     for (int i = threadIdx.x; i < 4096; i += 512)
         reinterpret_cast<float4*>(w3n)[i] = reinterpret_cast<const float4*>(W3)[i];
@@ -200,37 +237,48 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
         float* otile = dz2f + (size_t)u * FACL_UNIT_ELEMS;
 #pragma unroll
         for (int ro = 0; ro < 2; ++ro) {
-            // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j]
+            // ---- dense part on the MFMA: D^T[j][p] = sum_k G3[j][k] a2[p][k] + h3'[j], fp16x3 (common.h): G3 planes from LDS
+            //      (scaled by g3scale), a2 = relu(bn2(y2)) * 2^4 split in registers; 4 k-blocks x 3 products x 2 position tiles
             f32x16 acc[2];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4 hh = h3s[8 * ro + 2 * r4 + h];
+                const float hs = g3scale * FACL_H3_SA;                     // the accumulator runs at (G3 scale)(2^4)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    acc[ct][4 * r4] = hh.x; acc[ct][4 * r4 + 1] = hh.y; acc[ct][4 * r4 + 2] = hh.z; acc[ct][4 * r4 + 3] = hh.w;
+                    acc[ct][4 * r4] = hh.x * hs; acc[ct][4 * r4 + 1] = hh.y * hs; acc[ct][4 * r4 + 2] = hh.z * hs; acc[ct][4 * r4 + 3] = hh.w * hs;
                 }
             }
-            float4 scn = sc2[h], shn = sh2[h], fn = g3f[(ro * 2 * 4) * 64 + lane];
+            constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const int rt = st >> 2, r4 = st & 3;
-                const float4 sc = scn, sh = shn, f0 = fn;
-                if (st < 7) {
-                    const int rtn = (st + 1) >> 2, r4n = (st + 1) & 3;
-                    scn = sc2[8 * rtn + 2 * r4n + h]; shn = sh2[8 * rtn + 2 * r4n + h];
-                    fn = g3f[((ro * 2 + rtn) * 4 + r4n) * 64 + lane];
-                }
+            for (int kb = 0; kb < 4; ++kb) {
+                const int rt = kb >> 1, mm = kb & 1;
+                // (no register prefetch of the next block's fragments / tables here: the dense role has no registers to spare,
+                // and its SIMD partner, the scatter wave, fills the LDS latency)
+                const uint4 g0 = g3p[((ro * 4 + kb) * 2) * 64 + lane], g1 = g3p[((ro * 4 + kb) * 2 + 1) * 64 + lane];
+                const float4 sc0 = sc2[8 * rt + 4 * mm + h], sc1 = sc2[8 * rt + 4 * mm + 2 + h];
+                const float4 sh0 = sh2[8 * rt + 4 * mm + h], sh1 = sh2[8 * rt + 4 * mm + 2 + h];
                 __builtin_amdgcn_sched_barrier(0);
-                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                const float fa0[4] = {f0.x, f0.y, f0.z, f0.w};
+                const f16x8h gf[2] = {__builtin_bit_cast(f16x8h, g0), __builtin_bit_cast(f16x8h, g1)};
+                const float scv[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+                const float shv[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a20 = fmaxf(fmaf(scv[e], yv[0][rt][4 * r4 + e], shv[e]), 0.f);
-                    const float a21 = fmaxf(fmaf(scv[e], yv[1][rt][4 * r4 + e], shv[e]), 0.f);
-                    acc[0] = MFMA32(fa0[e], a20, acc[0]);
-                    acc[1] = MFMA32(fa0[e], a21, acc[1]);
+                for (int ct = 0; ct < 2; ++ct) {
+                    float a2[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) a2[t] = fmaxf(fmaf(scv[t], yv[ct][rt][8 * mm + t], shv[t]), 0.f) * FACL_H3_SA;
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) split_pair_h(a2[2 * t], a2[2 * t + 1], hi[t], lo[t]);
+                    const f16x8h af[2] = {as_f16x8(hi[0], hi[1], hi[2], hi[3]), as_f16x8(lo[0], lo[1], lo[2], lo[3])};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[ct] = MFMA_F16(gf[HA[t]], af[HB[t]], acc[ct]);   // (lo,hi) (hi,lo) (hi,hi)
                 }
             }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] *= g3uns;              // exact: a power of two
             // ---- combine, mask with z2 > 0, store dz2, accumulate dbeta2 / dgamma2
             float4 tn0 = *reinterpret_cast<const float4*>(&T[q * TP + 32 * ro + 4 * h]);
             float4 tn1 = *reinterpret_cast<const float4*>(&T[(32 + q) * TP + 32 * ro + 4 * h]);

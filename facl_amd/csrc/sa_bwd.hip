@@ -400,14 +400,32 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
         for (int e = 0; e < 4; ++e) { cfv[e] = cfn[e]; psv[e] = psn[e]; }
         if (u + nwaves < nunits) issue_loads(u + nwaves);   // (unconditional, as in k_sa_fwd3_sb: measured 5 % slower here)
         WAVE_LDS_FENCE();
-        // Gram: G[i][j] += sum_p a2[p][i] a2[p][j]; operands (lane = channel, k = position 32h+s)
+        // Gram: G[i][j] += sum_p a2[p][i] a2[p][j] on fp16x3 (common.h; both operands are activations: fixed scale 2^4, the
+        // accumulators run at 2^8 and are scaled back when the waves are combined).  Operand fragments (lane = channel q of
+        // the tile, k-slots = positions 16 ks + 8 h + t) come out of the padded tile with 8 ds_read_b32 each -- the same 128
+        // reads per unit the fp32 form issued -- and serve as A and as B operand alike; 36 MFMAs of 8 passes per unit instead
+        // of 96 of 16 (ablation: the fp32 Gram was 0.115 of the pass's 0.37 ms).
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const float a0 = T[(32 * h + s) * TP + q], a1 = T[(32 * h + s) * TP + 32 + q];
-            g00 = MFMA32(a0, a0, g00);
-            g01 = MFMA32(a0, a1, g01);
-            g11 = MFMA32(a1, a1, g11);
-            s2a += a0; s2b += a1;
+        for (int ks = 0; ks < 4; ++ks) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v0[t] = T[(16 * ks + 8 * h + t) * TP + q];
+                v1[t] = T[(16 * ks + 8 * h + t) * TP + 32 + q];
+            }
+            unsigned h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s2a += v0[2 * t] + v0[2 * t + 1];
+                s2b += v1[2 * t] + v1[2 * t + 1];
+                split_pair_h(v0[2 * t] * FACL_H3_SA, v0[2 * t + 1] * FACL_H3_SA, h0[t], l0[t]);
+                split_pair_h(v1[2 * t] * FACL_H3_SA, v1[2 * t + 1] * FACL_H3_SA, h1[t], l1[t]);
+            }
+            const f16x8h H0 = as_f16x8(h0[0], h0[1], h0[2], h0[3]), L0 = as_f16x8(l0[0], l0[1], l0[2], l0[3]);
+            const f16x8h H1 = as_f16x8(h1[0], h1[1], h1[2], h1[3]), L1 = as_f16x8(l1[0], l1[1], l1[2], l1[3]);
+            g00 = MFMA_F16(L0, H0, g00); g00 = MFMA_F16(H0, L0, g00); g00 = MFMA_F16(H0, H0, g00);   // smallest terms first
+            g01 = MFMA_F16(L0, H1, g01); g01 = MFMA_F16(H0, L1, g01); g01 = MFMA_F16(H0, H1, g01);
+            g11 = MFMA_F16(L1, H1, g11); g11 = MFMA_F16(H1, L1, g11); g11 = MFMA_F16(H1, H1, g11);
         }
         // sparse part of dW3 (same basic block as the Gram MFMAs: the scheduler sinks these FMAs into the MFMA shadow)
 #pragma unroll
@@ -441,9 +459,10 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
                 float* d00 = &gcomb[i * 64 + q];
                 float* d01 = &gcomb[i * 64 + 32 + q];
                 float* d11 = &gcomb[(32 + i) * 64 + 32 + q];
-                *d00 = (w == 0 ? 0.f : *d00) + g00[r];
-                *d01 = (w == 0 ? 0.f : *d01) + g01[r];
-                *d11 = (w == 0 ? 0.f : *d11) + g11[r];
+                constexpr float GU = 1.0f / (FACL_H3_SA * FACL_H3_SA);            // exact: 2^-8
+                *d00 = (w == 0 ? 0.f : *d00) + g00[r] * GU;
+                *d01 = (w == 0 ? 0.f : *d01) + g01[r] * GU;
+                *d11 = (w == 0 ? 0.f : *d11) + g11[r] * GU;
             }
             if (h == 0) {
                 scomb[q] = (w == 0 ? 0.f : scomb[q]) + s2ta;

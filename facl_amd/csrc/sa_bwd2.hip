@@ -36,6 +36,18 @@ constexpr int B2S_WAVES = 4;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// maximum of a non-negative value over the wave on the DPP crossbar (row_shr 1,2,4,8, row_bcast 15 / 31; no LDS round trip)
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float dpp_max_step(float v) {
+    const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false);
+    return fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = dpp_max_step<0x111, 0xf>(v); v = dpp_max_step<0x112, 0xf>(v); v = dpp_max_step<0x114, 0xf>(v); v = dpp_max_step<0x118, 0xf>(v);
+    v = dpp_max_step<0x142, 0xa>(v); v = dpp_max_step<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ bf16x8 tr_read_pair(const char* p_lo, const char* p_hi) {
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(p_lo));
@@ -44,7 +56,11 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const char* p_lo, const char* p_h
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int D>
+// H3: fp16x3 arithmetic (common.h).  W2 by 2^8, a1 by 2^4 (fixed); dy2 -- a gradient, and computed here -- by the power of
+// two that puts the maximum of the wave's half unit in [2^13, 2^14) (one DPP reduction per half unit, no LDS, no host).  The
+// da1 tiles are scaled back when they are consumed; dW2's contribution of a half unit is accumulated in a temporary tile
+// and added to the running sums with the inverse scale, so half units of different magnitude mix exactly.
+template <int D, bool H3>
 __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
     const float* __restrict__ dz2f, const float* __restrict__ y2f, const float* __restrict__ x, int nunits,
     const float* __restrict__ bw2 /* (4,64): scale2, A, B, mean2 */, const float* __restrict__ W2,
@@ -62,8 +78,13 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = W2[(k0 + j) * 64 + c1]; v[4 + j] = W2[(k0 + 8 + j) * 64 + c1]; }
         unsigned hi[4], mi[4], lo[4];
+        if (H3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
+            for (int j = 0; j < 4; ++j) { split_pair_h(v[2 * j] * FACL_H3_SW, v[2 * j + 1] * FACL_H3_SW, hi[j], mi[j]); lo[j] = 0u; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
+        }
         uint4* d = w2p + ((ct1 * 4 + kk) * 3) * 64 + ln;
         d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
@@ -131,8 +152,53 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                 zv[i] = *reinterpret_cast<const float4*>(zt + (i * 64 + lane) * 4);
                 yv[i] = *reinterpret_cast<const float4*>(yt + (i * 64 + lane) * 4);
             }
-            // ---- 1. dy2 -> bf16 planes: registers (A operand of da1) + LDS image (transposed A operand of dW2)
+            // ---- 1. dy2 -> 16-bit planes: registers (A operand of da1) + LDS image (transposed A operand of dW2)
             bf16x8 ap[4][3];                                // [k16 block][plane]
+            float uns_da = 1.f, uns_dw = 1.f;               // H3: inverse scales of this half unit's da1 / dW2 tiles
+            if (H3) {
+                float dyv[32];
+                float mx = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int rt = kk >> 1, m = kk & 1;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int r4 = 2 * m + t;
+                        const float4 z = zv[rt * 4 + r4], y = yv[rt * 4 + r4];
+                        const int ti = 8 * rt + 2 * r4 + h;
+                        const float4 s = sc2[ti], a = cA[ti], b = cB[ti], mm = mean2[ti];
+                        float* d = &dyv[8 * kk + 4 * t];
+                        d[0] = fmaf(s.x, z.x, fmaf(b.x, y.x - mm.x, a.x));
+                        d[1] = fmaf(s.y, z.y, fmaf(b.y, y.y - mm.y, a.y));
+                        d[2] = fmaf(s.z, z.z, fmaf(b.z, y.z - mm.z, a.z));
+                        d[3] = fmaf(s.w, z.w, fmaf(b.w, y.w - mm.w, a.w));
+                        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+                    }
+                }
+                mx = wave_max_nonneg(mx);
+                int se = 267 - (int)((__float_as_uint(mx) >> 23) & 0xff);      // 2^(13 - floor(log2 max)); NaN / inf pass through as such
+                se = se > 230 ? 230 : se;
+                const float sD = __uint_as_float((unsigned)se << 23);
+                uns_da = __uint_as_float((unsigned)(254 - se - 8) << 23);      // 1 / (sD 2^8)
+                uns_dw = __uint_as_float((unsigned)(254 - se - 4) << 23);      // 1 / (sD 2^4)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int rt = kk >> 1, m = kk & 1;
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int r4 = 2 * m + t;
+                        const float* d = &dyv[8 * kk + 4 * t];
+                        split_pair_h(d[0] * sD, d[1] * sD, hi[2 * t], lo[2 * t]);
+                        split_pair_h(d[2] * sD, d[3] * sD, hi[2 * t + 1], lo[2 * t + 1]);
+                        char* dst = st_row + rt * (32 * 64) + ((r4 ^ st_key) << 4);
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(hi[2 * t], hi[2 * t + 1]);
+                        *reinterpret_cast<uint2*>(dst + B2S_PLANE) = make_uint2(lo[2 * t], lo[2 * t + 1]);
+                    }
+                    ap[kk][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
+                    ap[kk][1] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
+                }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int rt = kk >> 1, m = kk & 1;
@@ -158,6 +224,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                 ap[kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
                 ap[kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
             }
+            }
             // ---- 2. da1[p][c1] = sum_c2 dy2[p][c2] W2[c2][c1]   (tiles: rows = positions, lane = c1)
             f32x16 da1[2];                                  // [c1 tile]
 #pragma unroll
@@ -168,9 +235,16 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                 for (int ct1 = 0; ct1 < 2; ++ct1) {
                     bf16x8 bfr[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, w2p[((ct1 * 4 + kk) * 3 + p) * 64 + lane]);
+                    for (int p = 0; p < (H3 ? 2 : 3); ++p) bfr[p] = __builtin_bit_cast(bf16x8, w2p[((ct1 * 4 + kk) * 3 + p) * 64 + lane]);
+                    if (H3) {
+                        constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) da1[ct1] = MFMA_BF16(ap[kk][PA[t]], bfr[PB[t]], da1[ct1]);
+                        for (int t = 0; t < 3; ++t)
+                            da1[ct1] = MFMA_F16(__builtin_bit_cast(f16x8h, ap[kk][HA[t]]), __builtin_bit_cast(f16x8h, bfr[HB[t]]), da1[ct1]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) da1[ct1] = MFMA_BF16(ap[kk][PA[t]], bfr[PB[t]], da1[ct1]);
+                    }
                 }
             WAVE_LDS_FENCE();                               // xs4 / image written by this wave are visible to its reads
             // ---- 3. a1, dz1, R1 in the (rows = positions, lane = c1) layout
@@ -185,7 +259,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                     v = fmaf(w1r[ct1].z, xv.z, v);
                     if (D == 4) v = fmaf(w1r[ct1].w, xv.w, v);
                     a1v[ct1][r] = fmaxf(v, 0.f);
-                    const float dz = v > 0.f ? da1[ct1][r] : 0.f;
+                    const float dz = v > 0.f ? (H3 ? da1[ct1][r] * uns_da : da1[ct1][r]) : 0.f;
                     r1[ct1][0] = fmaf(xv.x, dz, r1[ct1][0]);
                     r1[ct1][1] = fmaf(xv.y, dz, r1[ct1][1]);
                     r1[ct1][2] = fmaf(xv.z, dz, r1[ct1][2]);
@@ -194,6 +268,47 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                 }
             }
             // ---- 4. dW2 += dy2^T a1
+            if (H3) {
+                f16x8h bx[2][2][2];                         // [k-step s][c1 tile][plane]: a1 rows 16s + 8(j>>2) + 4h + (j&3), scaled 2^4
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int ct1 = 0; ct1 < 2; ++ct1) {
+                        unsigned hi[4], lo[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            split_pair_h(a1v[ct1][8 * s + 2 * j] * FACL_H3_SA, a1v[ct1][8 * s + 2 * j + 1] * FACL_H3_SA, hi[j], lo[j]);
+                        bx[s][ct1][0] = as_f16x8(hi[0], hi[1], hi[2], hi[3]);
+                        bx[s][ct1][1] = as_f16x8(lo[0], lo[1], lo[2], lo[3]);
+                    }
+                constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    f16x8h at[2][2];                        // [k-step s][plane]: dy2^T [row c2 = 32 rt + q][k = position]
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int off = (rt * 32 + 16 * s) * 64;
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            at[s][p] = __builtin_bit_cast(f16x8h, tr_read_pair(tr_ptr[0] + p * B2S_PLANE + off, tr_ptr[1] + p * B2S_PLANE + off));
+                    }
+                    f32x16 tw[2];                           // this half unit's contribution at scale sD 2^4: two tiles interleaved
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tw[0][r] = tw[1][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            tw[0] = MFMA_F16(at[s][HA[t]], bx[s][0][HB[t]], tw[0]);
+                            tw[1] = MFMA_F16(at[s][HA[t]], bx[s][1][HB[t]], tw[1]);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        dw2[rt][0][r] = fmaf(tw[0][r], uns_dw, dw2[rt][0][r]);
+                        dw2[rt][1][r] = fmaf(tw[1][r], uns_dw, dw2[rt][1][r]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 bx[2][3];                            // B operand of k-step s: a1 rows 16s + 8(j>>2) + 4h + (j&3)
@@ -218,6 +333,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                         dw2[rt][1] = MFMA_BF16(at[PA[t]], bx[1][PB[t]], dw2[rt][1]);
                     }
                 }
+            }
             }
             WAVE_LDS_FENCE();                               // the next half unit overwrites the image (and xs4 after ct = 1)
         }
@@ -256,14 +372,24 @@ int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, 
     const size_t lds = (1536 + 64 + B2S_WAVES * 64) * sizeof(float4) + B2S_WAVES * (size_t)B2S_IMG;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_sa_bwd2_sb<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_sa_bwd2_sb<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+        const void* fns[4] = {(const void*)k_sa_bwd2_sb<4, true>, (const void*)k_sa_bwd2_sb<3, true>,
+                              (const void*)k_sa_bwd2_sb<4, false>, (const void*)k_sa_bwd2_sb<3, false>};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_done = true;
     }
     static const int rev = getenv("FACL_BWD2_REV") ? atoi(getenv("FACL_BWD2_REV")) : 1;
-    if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4>), dim3(grid), dim3(64 * B2S_WAVES), lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
-    else hipLaunchKernelGGL((k_sa_bwd2_sb<3>), dim3(grid), dim3(64 * B2S_WAVES), lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+    static const int h3 = getenv("FACL_BWD_H3") ? atoi(getenv("FACL_BWD_H3")) : 1;     // 0: bf16x6 (A/B)
+    const dim3 g(grid), b(64 * B2S_WAVES);
+    if (h3) {
+        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+    } else {
+        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, false>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, false>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+    }
     return facl_launch_status();
 }
 

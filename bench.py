@@ -314,8 +314,12 @@ def main():
     rank, world = fdist.init_from_env()
     if a.rehearse_dp and world == 1:
         import torch.distributed as tdist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
+        import socket
+        with socket.socket() as sk:                          # a port nobody holds (a fixed one can sit in TIME_WAIT after a torchrun)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
         tdist.init_process_group("nccl", rank=0, world_size=1)
         fdist.is_distributed = lambda: True                 # is_distributed() is world_size > 1: force the hooks on
         import facl_amd.train_common as _tc
@@ -433,6 +437,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline_dense(a) if a.config == "dense" else cpu_baseline(a)
     if world > 1:
         torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    elif a.rehearse_dp:
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

@@ -189,6 +189,18 @@ def require_cuda(*tensors):
             raise RuntimeError("facl_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
 
 
+# ---- debug taps: integer side outputs of a forward that no caller of the reference's interface ever sees ----------------------
+# When TAPS is a dict (tests: tests/helpers.routing_taps), forward passes drop the argmax tensors of their max-pools here
+# ("sa_arg": max over the K neighbours, "seg_arg": my_max_pool over the S centroids, "view_arg": the view maximum), so a
+# reference evaluation can route its gradients through the same positions (tie-proof gradient parity).
+TAPS = None
+
+
+def tap(name, t):
+    if TAPS is not None:
+        TAPS[name] = t.detach().clone()
+
+
 # ---- optional in-step kernel timing (bench.py's roofline section) ----------------------------------------------------
 # When TIMING is a dict, `timed(label)` brackets the launches issued inside the `with` block with HIP events on the
 # launch stream (eager execution only: events cannot be recorded inside a graph replay) and appends the event pair to

@@ -8,6 +8,7 @@ global batch:
   2. SyncBN: all-reduce of the (sum, sumsq) / (dbeta, dgamma) fp64 buffers between kernel passes,
   3. gradient all-reduce (one flat 9.4 MB bucket), averaged.
 """
+import datetime
 import os
 
 import torch
@@ -27,8 +28,30 @@ def init_from_env(backend=None):
     if backend is None:
         # "nccl" IS RCCL on ROCm.  FACL_DIST_BACKEND=gloo rehearses the N>1 path on a single-GPU box.
         backend = os.environ.get("FACL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # A mismatched or missing collective must RAISE, not wait: the default process-group timeout is 10 minutes, longer than
+    # any launcher's patience.  With the watchdog's asynchronous error handling a timed-out RCCL call tears the rank down
+    # (non-zero exit), the launcher then stops the other ranks.  FACL_DIST_TIMEOUT_S overrides (first-iteration RCCL
+    # set-up of 8 ranks takes seconds, a 3 ms step never legitimately waits two minutes).
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    timeout = datetime.timedelta(seconds=float(os.environ.get("FACL_DIST_TIMEOUT_S", "120")))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world
+
+
+class CaptureAborted(RuntimeError):
+    """Raised on a rank that learns at a vote that ANOTHER rank's graph capture failed (its own was fine so far)."""
+
+
+def vote(ok, group=None):
+    """Agreement across ranks: MIN all-reduce of a success flag.  Returns True iff every rank voted True.  Used only while
+    a step is being captured / validated (never inside the replayed step), so its host round trip costs nothing later.
+    RCCL reduces device tensors, gloo host tensors."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
+    on_dev = dist.get_backend(group) == "nccl"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
 
 
 class GraphSegments:
@@ -43,12 +66,30 @@ class GraphSegments:
     collectives really execute (on garbage: no kernel of the step has run), which keeps the ranks in lockstep.
 
     Cuts happen wherever the step's Python runs -- including the autograd engine's worker thread -- hence the relaxed
-    capture mode (a capture begun on one thread is ended on another)."""
+    capture mode (a capture begun on one thread is ended on another).
+
+    Failure protocol (a capture that fails on ONE rank must not leave the others replaying segments against its eager
+    launches: mismatched collectives = a hang).  While capturing, every cut and the end of the capture carry one extra
+    tiny collective, a `vote`: a rank whose segment raised votes "failed" exactly once (train_common.GraphedStep does, from
+    its handler), which pairs with the others' next vote; they raise CaptureAborted there.  Up to that vote every rank has
+    issued the same collectives, so all ranks leave the capture at the same point of the collective sequence and can
+    continue TOGETHER on eager launches.  A failure inside a collective itself cannot be voted on: the process-group
+    timeout (init_from_env) bounds it."""
 
     def __init__(self):
         self.pool = torch.cuda.graph_pool_handle()
         self.items = []                 # CUDAGraph objects and zero-argument callables, in replay order
         self.cur = None
+        self.voting = dist.is_available() and dist.is_initialized()
+        self.ncuts = 0
+        # test hooks: "<rank>:<cut>" -- that rank's capture raises (FAIL) or the process dies (EXIT) when it reaches that cut
+        self._inject = {}
+        for key in ("FACL_TEST_CAPTURE_FAIL", "FACL_TEST_CAPTURE_EXIT"):
+            v = os.environ.get(key)
+            if v and self.voting:
+                r, c = (int(x) for x in v.split(":"))
+                if r == dist.get_rank():
+                    self._inject[key] = c
 
     def begin(self):
         self.cur = torch.cuda.CUDAGraph()
@@ -59,14 +100,25 @@ class GraphSegments:
         self.items.append(self.cur)
         self.cur = None
 
+    def _agree(self):
+        if self.voting and not vote(True):
+            raise CaptureAborted("graph capture failed on another rank (after %d collectives)" % self.ncuts)
+
     def cut(self, fn):
+        if self._inject.get("FACL_TEST_CAPTURE_EXIT") == self.ncuts:
+            os._exit(17)
+        if self._inject.get("FACL_TEST_CAPTURE_FAIL") == self.ncuts:
+            raise RuntimeError("injected capture failure at cut %d (FACL_TEST_CAPTURE_FAIL)" % self.ncuts)
         self._close()
+        self._agree()
         fn()
         self.items.append(fn)
+        self.ncuts += 1
         self.begin()
 
     def end(self):
         self._close()
+        self._agree()
 
     def abort(self):
         if self.cur is not None:
@@ -87,6 +139,32 @@ class GraphSegments:
     @property
     def n_graphs(self):
         return sum(isinstance(it, torch.cuda.CUDAGraph) for it in self.items)
+
+
+class CaptureFailed(RuntimeError):
+    """The segmented capture failed -- on EVERY rank, at the same point of the collective sequence (see GraphSegments)."""
+
+
+def run_capture(rec, body, rank=0):
+    """Run `body()` with `rec` recording (cut at every collective).  Returns body's result, or raises CaptureFailed on all
+    ranks together: the rank whose segment raised votes "failed" once, which pairs with the next vote of the others."""
+    set_recorder(rec)
+    try:
+        rec.begin()
+        out = body()
+        rec.end()
+        return out
+    except CaptureAborted as e:                  # learnt at a vote: the failure is already agreed on
+        rec.abort()
+        raise CaptureFailed(str(e)) from e
+    except Exception as e:                       # this rank's segment raised: tell the others at their next vote
+        rec.abort()
+        if rec.voting:
+            vote(False)
+        raise CaptureFailed("graph-segment capture failed on rank %d after %d collectives: %s: %s"
+                            % (rank, rec.ncuts, type(e).__name__, e)) from e
+    finally:
+        set_recorder(None)
 
 
 _RECORDER = None       # the GraphSegments being captured, or None (eager)
@@ -234,6 +312,11 @@ class GradSync:
     def _arm(self):
         self.pending = len(self.early)
         self.work, self.flat = None, None
+
+    def reset(self):
+        """After a step that did not run to its end (a failed graph capture): forget the half-counted hooks."""
+        if self.early is not None:
+            self._arm()
 
     def _hook(self, _p):
         self.pending -= 1

@@ -147,6 +147,7 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         _lib.check(fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
                                     _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
                                     _lib.ptr(ws), st), "facl_sa_fwd3")
+    _lib.tap("sa_arg", arg)
     if training:
         if reduce_fn is not None:
             reduce_fn(sums3)

@@ -245,6 +245,7 @@ class _LinearBNSegmax(torch.autograd.Function):
             bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
             _lib.check(lib.facl_rows_segmax(_lib.ptr(y), M, S, C, _lib.ptr(bnc), _lib.ptr(xpre), _lib.ptr(arg),
                                             _lib.stream()), "facl_rows_segmax")
+        _lib.tap("seg_arg", arg)
         ctx.save_for_backward(h, W, y, bnc, xpre, arg)
         ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
         ctx.mark_non_differentiable(arg)
@@ -326,6 +327,7 @@ class _FCHead(torch.autograd.Function):
         h[:M].copy_(x_pre)
         arg = _lib.empty((B, Cin), dtype=torch.int32, device=x_pre.device)
         _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, Cin, h[M:].data_ptr(), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
+        _lib.tap("view_arg", arg)
         W1, W2 = W1.contiguous(), W2.contiguous()
         y, _ = gemm_fwd(h, W1, b1, prec=ctx.prec)
         R, C = y.shape
@@ -659,6 +661,7 @@ class _Net3DV3(torch.autograd.Function):
         xpre = _lib.empty((M, C), dtype=torch.float32, device=pooled.device)
         _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(xpre), _lib.stream()),
                    "facl_sa_pool")
+        _lib.tap("seg_arg", arg)
         ctx.save_for_backward(pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg)
         ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
         return xpre

@@ -177,6 +177,25 @@ class ContrastiveStep:
         return loss, loss_c, loss_circle
 
 
+class GraphCaptureFailed(RuntimeError):
+    """The step could not be captured (or its replay did not reproduce the eager step).  Model, BatchNorm buffers and
+    optimizer state are back at their values from before the attempt.  Under data parallelism EVERY rank raises it at the
+    same point of the collective sequence (facl_amd/dist.py: GraphSegments' failure protocol), so all ranks may continue
+    together on eager launches; any other exception out of GraphedStep under world > 1 is not agreed on and must end the rank."""
+
+
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(dev):
+    """One side stream per device for warm-up + capture (the scratch workspace of the HIP passes is keyed by stream:
+    a fresh stream per GraphedStep would pin another workspace each time)."""
+    key = (dev.type, dev.index)
+    if key not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _CAPTURE_STREAMS[key]
+
+
 class GraphedStep:
     """The whole training iteration (grouping -> forward -> losses -> backward -> Adam) captured once into a HIP
     graph and replayed: ~250 kernel launches per step collapse into one graph launch, so the step is no longer bound
@@ -184,23 +203,63 @@ class GraphedStep:
     them replay as graphs (collectives stay eager: facl_amd/dist.py: GraphSegments); the optimizer must keep its step counter on the device
     (facl_amd.optim.FusedAdam, or torch.optim.Adam(capturable=True, lr=<tensor>)).  Learning-rate changes between
     replays: FusedAdam's device-side lr is refreshed before every replay (`sync_lr`); with torch's capturable Adam only
-    a TENSOR lr updated in place is seen by the graph."""
+    a TENSOR lr updated in place is seen by the graph.
 
-    def __init__(self, step, example_points, G, restore=False):
+    Failure: GraphCaptureFailed, with the training state restored (the three warm-up calls are REAL optimizer steps).  Under
+    data parallelism the segmented replay is additionally VALIDATED before it is trusted: one eager step and one replayed
+    step from the same state must give the same loss on every rank (`validate`, default on when distributed)."""
+
+    def __init__(self, step, example_points, G, restore=False, validate=None):
         """`restore`: put parameters, BatchNorm buffers and optimizer state back to what they were before the three
         warm-up steps, so that a training run continues exactly where an eager run would be."""
         self.step, self.G = step, G
         dev = example_points.device
         self.points = example_points.clone()
         self.order = torch.arange(G, dtype=torch.long, device=dev)
-        snap = None
+        self.graph = self.segments = None
+        distributed = fdist.is_distributed()
+        validate = distributed if validate is None else validate
+        snap = self._snapshot()
+        try:
+            self._capture(distributed, dev)
+            if validate and self.segments is not None:
+                self._validate()
+        except Exception:
+            self.graph = self.segments = None
+            torch.cuda.synchronize()
+            self._restore(snap)                          # three real optimizer steps (and maybe more) ran on `example_points`
+            step.optimizer.zero_grad(set_to_none=True)
+            if step.grad_sync is not None:
+                step.grad_sync.reset()
+            raise
         if restore:
-            snap = ({k: v.detach().clone() for k, v in step.netR.state_dict().items()},
-                    step.optimizer.state_dict() if hasattr(step.optimizer, "_step") else None)
-            if snap[1] is not None:                       # FusedAdam.state_dict() shares its moment tensors: deep copy
-                snap = (snap[0], {"state": {i: {k: v.clone() for k, v in st.items()} for i, st in snap[1]["state"].items()},
-                                  "param_groups": snap[1]["param_groups"]})
-        s = torch.cuda.Stream()
+            self._restore(snap)
+
+    # ---- training state = parameters + BatchNorm buffers (+ their host-side counters) + optimizer state
+    def _snapshot(self):
+        step = self.step
+        net = {k: v.detach().clone() for k, v in step.netR.state_dict().items()}
+        opt = None
+        if hasattr(step.optimizer, "_step"):             # FusedAdam.state_dict() shares its moment tensors: deep copy
+            sd = step.optimizer.state_dict()
+            opt = {"state": {i: {k: v.clone() for k, v in st.items()} for i, st in sd["state"].items()},
+                   "param_groups": sd["param_groups"]}
+        return net, opt, [(m, m.steps) for m in self._bn_modules()]
+
+    def _restore(self, snap):
+        net, opt, steps = snap
+        with torch.no_grad():                            # in place: a captured graph holds the addresses of these tensors
+            cur = self.step.netR.state_dict()
+            for k, v in net.items():
+                cur[k].copy_(v)
+        for m, n in steps:
+            m.steps = n
+        if opt is not None:
+            self.step.optimizer.load_state_dict(opt)
+
+    def _capture(self, distributed, dev):
+        step = self.step
+        s = _capture_stream(dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                       # warm-up on a side stream (allocator + lazy inits)
             for _ in range(3):
@@ -211,41 +270,45 @@ class GraphedStep:
         # would run ahead of the running-statistics updates: restore them afterwards.  NOTE: the 3 warm-up calls above
         # are REAL optimizer steps on `example_points` (they also settle the allocator and Adam's lazy state).
         saved = [(m, m.steps) for m in self._bn_modules()]
-        if fdist.is_distributed():
+        if distributed:
             # data parallel: the capture is cut at every collective (facl_amd/dist.py: GraphSegments) -- kernel segments
             # replay as graphs, the collectives in between are ordinary eager RCCL calls on the same stream
-            self.graph = None
-            self.segments = rec = fdist.GraphSegments()
+            rec = fdist.GraphSegments()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                fdist.set_recorder(rec)
-                try:
-                    rec.begin()
-                    self.out = step.run(self.points, self.order)
-                    rec.end()
-                except BaseException:
-                    rec.abort()
-                    raise
-                finally:
-                    fdist.set_recorder(None)
+            try:
+                with torch.cuda.stream(s):
+                    self.out = fdist.run_capture(rec, lambda: step.run(self.points, self.order), step.rank)
+            except fdist.CaptureFailed as e:             # agreed on by every rank (facl_amd/dist.py: run_capture)
+                raise GraphCaptureFailed(str(e)) from e
+            self.segments = rec
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
         else:
-            self.segments = None
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = step.run(self.points, self.order)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph, stream=s):
+                    self.out = step.run(self.points, self.order)
+            except Exception as e:
+                raise GraphCaptureFailed("graph capture failed: %s: %s" % (type(e).__name__, e)) from e
+            self.graph = graph
         for m, n in saved:
             m.steps = n
-        if snap is not None:
-            with torch.no_grad():                        # in place: the graph holds the addresses of these tensors
-                cur = step.netR.state_dict()
-                for k, v in snap[0].items():
-                    cur[k].copy_(v)
-            for m in self._bn_modules():
-                m.steps = int(m.num_batches_tracked) if hasattr(m, "num_batches_tracked") else m.steps
-            if snap[1] is not None:
-                step.optimizer.load_state_dict(snap[1])
+
+    def _validate(self):
+        """One eager step and one replayed step from the same state must agree (they run the same kernels in the same
+        order: the losses are equal to the last bits) -- on EVERY rank, or nobody replays.  What this catches is what a
+        one-GPU rehearsal cannot: an ordering lost between the collective library's stream and the next graph segment."""
+        step = self.step
+        snap = self._snapshot()
+        loss_e = float(step.run(self.points, self.order)[0])
+        self._restore(snap)
+        self.segments.replay()
+        loss_g = float(self.out[0])
+        self._restore(snap)
+        ok = loss_e == loss_e and abs(loss_e - loss_g) <= 1e-5 * abs(loss_e)
+        if not fdist.vote(ok):
+            raise GraphCaptureFailed("replayed graph segments do not reproduce the eager step (this rank: eager loss %r, "
+                                     "replayed %r)" % (loss_e, loss_g))
 
     def _bn_modules(self):
         return [m for m in self.step.netR.modules() if hasattr(m, "count_batch")]
@@ -318,10 +381,13 @@ def run(default_branch, ckpt_pattern, args=None):
             if run_step is step and opt.graph and not (opt.swa_if or opt.cld_if):
                 try:                                     # capture on the first batch; state restored: same trajectory as eager
                     run_step = GraphedStep(step, out_points, num_crop, restore=True)
-                except Exception as e:                   # keep training on eager launches
-                    print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e))
+                except GraphCaptureFailed as e:
+                    # training state is back at its pre-capture values and, under data parallelism, EVERY rank is here
+                    # (GraphSegments' votes): all ranks continue together on eager launches.  Anything else raised under
+                    # world > 1 is not agreed on across ranks: it propagates, the rank exits non-zero and the launcher
+                    # stops the others (no rank is left replaying segments against another's eager collectives).
+                    print("graph capture failed (%s); running eager" % e)
                     opt.graph = 0
-                    netR.zero_grad(set_to_none=True)
             loss, _, _ = run_step(out_points, epoch)
             torch.cuda.synchronize()
             loss_sigma += loss.item()

@@ -52,3 +52,86 @@ def golden_view_clips(g):
     for tag, (cseed, is64, P, Kp, R1, R2) in zip("abcd", g["cases"].tolist()):
         out.append((tag, synth_clip(cseed, np.float64 if is64 else np.float32, P, Kp, R1, R2)))
     return out
+
+
+# ---- plain torch-fp64 evaluation of the encoder on grouped rows, optionally with the KERNEL's max-pool routing -----------
+def forward64(x_rows, centers, sd, G, S, K, dev, routing=None, grad=False, dtype=None):
+    """cn3d_model_conbag.py:213-234 in fp64 (matmuls, train-mode BN with batch statistics, ReLU, the three max-pools) on
+    (P,D) grouped rows / (M*S,3) centres.  Returns (x, x_global, stats, q, ties).
+
+    `routing` = {"sa_arg" (M*S,256), "seg_arg" (M,1024), "view_arg" (B,1024)}: the argmax indices the HIP forward chose.
+    Each max-pool then GATHERS at those indices instead of taking its own maximum, so the autograd graph routes the gradient
+    exactly as the kernels do and a comparison of gradients no longer depends on which side of a numerical near-tie each
+    arithmetic lands on.  `ties[name]` = the largest distance of a gathered value from the true fp64 maximum, relative to
+    max(|max|, mean |activation|): the test that every differing decision WAS a tie.
+    `grad`: parameters require grad (q[k].grad after a backward).  `dtype` (default float64): torch.float32 gives the
+    "plain torch fp32 with the same routing" twin -- the conditioning yardstick of a gradient comparison."""
+    import torch
+    dtype = torch.float64 if dtype is None else dtype
+    q = {k: torch.as_tensor(v).to(dev).to(dtype) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    if grad:
+        for k in q:
+            if "running" not in k:
+                q[k].requires_grad_(True)
+    stats, ties = {}, {}
+
+    def bn_train(y, gamma, beta, key):
+        P = y.shape[0]
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        stats[key] = (mean.detach(), (var * (P / (P - 1.0))).detach())
+        return (y - mean) / torch.sqrt(var + 1e-5) * gamma + beta
+
+    def pool(h3, idx, name):                                                   # (R, L, C) -> (R, C) over L
+        mx = h3.max(dim=1).values
+        if idx is None:
+            return mx
+        got = torch.gather(h3, 1, idx.long().view(h3.shape[0], 1, h3.shape[2])).squeeze(1)
+        with torch.no_grad():
+            scale = torch.maximum(mx.abs(), h3.abs().mean())
+            ties[name] = float(((mx - got).abs() / scale).max())
+            ties[name + "_flips"] = int((idx.long().view(h3.shape[0], h3.shape[2]) != h3.argmax(dim=1)).sum())
+        return got
+
+    r = routing or {}
+    h = x_rows.to(dtype)
+    for li in (0, 3, 6):                                                       # net3DV_1 (:43-58)
+        W = q[f"net3DV_1.{li}.weight"].reshape(q[f"net3DV_1.{li}.weight"].shape[0], -1)
+        y = h @ W.t() + q[f"net3DV_1.{li}.bias"]
+        h = torch.relu(bn_train(y, q[f"net3DV_1.{li + 1}.weight"], q[f"net3DV_1.{li + 1}.bias"], f"net3DV_1.{li + 1}"))
+        del y
+    MS = h.shape[0] // K
+    pooled = pool(h.view(MS, K, 256), r.get("sa_arg"), "sa")
+    del h
+    h = torch.cat((centers.to(dtype), pooled), dim=1)                           # :219
+    for li in (0, 3, 6):                                                       # net3DV_3 (:61-77)
+        W = q[f"net3DV_3.{li}.weight"].reshape(q[f"net3DV_3.{li}.weight"].shape[0], -1)
+        y = h @ W.t() + q[f"net3DV_3.{li}.bias"]
+        h = torch.relu(bn_train(y, q[f"net3DV_3.{li + 1}.weight"], q[f"net3DV_3.{li + 1}.bias"], f"net3DV_3.{li + 1}"))
+    M = MS // S
+    B = M // G
+    x_pre = pool(h.view(M, S, 1024), r.get("seg_arg"), "seg")                  # :222
+    # :225-226 (rows are view-major g*B+b): max over all G*S local features of a clip = max over the views of the view maxima
+    xg_pre = pool(x_pre.view(G, B, 1024).transpose(0, 1), r.get("view_arg"), "view")
+
+    def head(t, key):                                                          # netR_FC (:201-207), two BN calls (:228-229)
+        y = t @ q["netR_FC.0.weight"].t() + q["netR_FC.0.bias"]
+        a = torch.relu(bn_train(y, q["netR_FC.1.weight"], q["netR_FC.1.bias"], key))
+        return a @ q["netR_FC.3.weight"].t() + q["netR_FC.3.bias"]
+    x = head(x_pre, "fc_a")
+    xg = head(xg_pre, "fc_b")
+    return x, xg, stats, q, ties
+
+
+class routing_taps:
+    """with routing_taps() as r: <HIP forward> -> r = {"sa_arg", "seg_arg", "view_arg"}: the argmax tensors of the three
+    max-pools of that forward (facl_amd/_lib.py: tap)."""
+
+    def __enter__(self):
+        from facl_amd import _lib
+        self.prev, _lib.TAPS = _lib.TAPS, {}
+        return _lib.TAPS
+
+    def __exit__(self, *exc):
+        from facl_amd import _lib
+        _lib.TAPS = self.prev
+        return False

@@ -196,6 +196,49 @@ def test_bench_gpus_flag_launches_ranks_or_fails_loudly():
     assert line["value"] > 0 and line["roofline"]["ms_per_launch"] > 0
 
 
+def _bench_2rank_gloo(extra_env, timeout=600):
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.update(FACL_DIST_BACKEND="gloo", FACL_DIST_TIMEOUT_S="60")
+    env.update(extra_env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--B", "2", "--T", "4",
+           "--N", "512", "--no-cpu-baseline"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    dt = time.time() - t0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, (json.loads(lines[-1]) if lines else None), dt
+
+
+def test_capture_failure_on_one_rank_all_ranks_go_eager_together():
+    """rank 1's graph-segment capture raises after the 3rd collective.  The ranks must agree on the
+    failure (facl_amd/dist.py: GraphSegments votes), restore their training state and finish the measurement TOGETHER on
+    eager launches -- inside the first child run, no hang, no mismatched collective."""
+    r, line, dt = _bench_2rank_gloo({"FACL_TEST_CAPTURE_FAIL": "1:3"})
+    print("returned after %.1f s" % dt)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["launch"].startswith("eager (graph capture failed"), line["config"]["launch"]
+    assert "retrying once" not in r.stderr                        # agreed in-process, the launcher's second attempt was not needed
+    assert dt < 90, dt
+
+
+def test_rank_death_during_capture_launcher_retries_once_on_eager_launches():
+    """rank 1 DIES in the middle of the capture (no vote possible).  torch.distributed.run stops the other
+    rank (or its 60 s process-group timeout does), `bench.py --gpus 2` starts ONE fresh child tree with --graph 0 and reports
+    that line, marked as such."""
+    r, line, dt = _bench_2rank_gloo({"FACL_TEST_CAPTURE_EXIT": "1:3"})
+    print("returned after %.1f s" % dt)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "retrying once with --graph 0" in r.stderr
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["launch"].startswith("eager (graph-segment run failed"), line["config"]["launch"]
+    assert dt < 150, dt
+
+
 def _run_graphed_vs_eager(clip, G):
     """Two identical models: one stepped eagerly, one through GraphedStep (segmented capture under data parallelism); three
     optimizer steps each on the same clips; returns (eager losses, graph losses, max relative parameter difference,

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, max_rel_rows, rel_err
+from helpers import forward64, load_golden, max_rel_rows, rel_err, routing_taps
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -87,7 +87,8 @@ def test_c1_golden_forward_loss_backward_adam(tag, D, neg):
     optim = torch.optim.Adam(net.parameters(), lr=0.0003, betas=(0.5, 0.999), eps=1e-06)
     losses = []
     for it in range(3):
-        x, code, x_nor, x_global = net(xt, yt, 1)
+        with routing_taps() as routing:                  # the argmax tensors of the three max-pools of this forward
+            x, code, x_nor, x_global = net(xt, yt, 1)
         loss_c = global_contrast(G, x_global, x, opt)
         loss_circle = circle_contrast(G, x, B, order=g["order"])
         loss = loss_circle + loss_c
@@ -140,6 +141,32 @@ def test_c1_golden_forward_loss_backward_adam(tag, D, neg):
                 # 2e-4 on the GPU box's CPU, 7e-3 in the build container for the SAME oracle code.  The
                 # kernel-level gradient check (same upstream gradient, no flips) is test_gpu_sa_mlp.py: 3e-7.
                 assert e_mine <= max(3 * e_t32, 5e-3), k
+            # THE gradient bound: fp64 evaluation of the same graph on the same grouped rows, its three
+            # max-pools routed through the positions the HIP forward chose (each verified to be a tie of the fp64 values), so
+            # the comparison is pure arithmetic: every parameter tensor within 1e-4 (of its norm, floored at 1 % of the largest)
+            from oracle import loss as OL
+            from oracle.weights import formula_state_dict
+            xr, cr = xt.permute(0, 2, 3, 1).reshape(-1, D), yt.permute(0, 2, 1, 3).reshape(-1, 3)
+            def routed(dtype):
+                xr_, xg_, _, q_, ties_ = forward64(xr, cr, formula_state_dict(D, neg_gamma=neg), G, S, K, DEV, routing=routing,
+                                                   grad=True, dtype=dtype)
+                (OL.global_contrast(G, xg_, xr_, B) + OL.circle_contrast(G, xr_, B, g["order"])).backward()
+                return q_, ties_
+            q64, ties = routed(torch.float64)
+            q32, _ = routed(torch.float32)               # plain torch fp32, same routing: the conditioning yardstick
+            print("ties", ties)
+            assert max(ties["sa"], ties["seg"], ties["view"]) < 1e-5, ties
+            gmax64 = max(float(q64[k].grad.norm()) for k, _ in net.named_parameters() if q64[k].grad is not None)
+            for k, p in net.named_parameters():
+                if k in PRE_BN_BIAS or q64[k].grad is None or k == "net3DV_3.7.bias":   # mathematically ~0 gradients
+                    continue
+                r = q64[k].grad.reshape(p.shape)
+                err = float((p.grad.double() - r).norm())
+                e32 = float((q32[k].grad.reshape(p.shape).double() - r).norm())
+                print(f"grad {k:20s} vs routed fp64: {err / float(r.norm()):.2e}   torch-fp32 (same routing) {e32 / float(r.norm()):.2e}")
+                # 1e-4, or the distance of torch's own fp32 autograd of the same routed graph where the quantity is
+                # ill-conditioned (train-mode BatchNorm over B = 4 rows in netR_FC's second call)
+                assert err <= max(1e-4 * max(float(r.norm()), 1e-2 * gmax64), e32), (k, err, e32, float(r.norm()))
             sd = net.state_dict()
             for k in sd:
                 if "running_" in k:

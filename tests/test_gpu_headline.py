@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import max_rel_rows, rel_err
+from helpers import forward64, max_rel_rows, rel_err, routing_taps
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -19,48 +19,6 @@ def _opt(D, B, N):
     return SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64,
                            sample_num_level2=64, INPUT_FEATURE_NUM=D, Num_Class=512, batchSize=B,
                            pooling="concatenation", SAMPLE_NUM=N)
-
-
-def _bn_train64(y, gamma, beta, stats, key):
-    """train-mode BatchNorm over the rows of y (fp64): biased variance to normalise, unbiased one for the running buffer."""
-    P = y.shape[0]
-    mean, var = y.mean(0), y.var(0, unbiased=False)
-    stats[key] = (mean, var * (P / (P - 1.0)))
-    return (y - mean) / torch.sqrt(var + 1e-5) * gamma + beta
-
-
-def _forward64(x_rows, centers, sd, G, S, K):
-    """cn3d_model_conbag.py:213-234 in fp64 on (P,D) grouped rows / (M*S,3) centres.  Returns x, x_global, stats."""
-    q = {k: torch.as_tensor(v).to(DEV).double() for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
-    stats = {}
-    h = x_rows.double()
-    for li in (0, 3, 6):                                                       # net3DV_1 (:43-58)
-        W = q[f"net3DV_1.{li}.weight"].reshape(q[f"net3DV_1.{li}.weight"].shape[0], -1)
-        y = h @ W.t() + q[f"net3DV_1.{li}.bias"]
-        del h
-        h = torch.relu_(_bn_train64(y, q[f"net3DV_1.{li + 1}.weight"], q[f"net3DV_1.{li + 1}.bias"], stats, f"net3DV_1.{li + 1}"))
-        del y
-    MS = h.shape[0] // K
-    pooled = h.view(MS, K, 256).max(dim=1).values
-    del h
-    h = torch.cat((centers.double(), pooled), dim=1)                           # :219
-    for li in (0, 3, 6):                                                       # net3DV_3 (:61-77)
-        W = q[f"net3DV_3.{li}.weight"].reshape(q[f"net3DV_3.{li}.weight"].shape[0], -1)
-        y = h @ W.t() + q[f"net3DV_3.{li}.bias"]
-        h = torch.relu_(_bn_train64(y, q[f"net3DV_3.{li + 1}.weight"], q[f"net3DV_3.{li + 1}.bias"], stats, f"net3DV_3.{li + 1}"))
-    M = MS // S
-    B = M // G
-    local = h.view(M, S, 1024)
-    x_pre = local.max(dim=1).values                                            # :222
-    xg_pre = x_pre.view(G, B, 1024).max(dim=0).values                          # :225-226 (rows are view-major g*B+b)
-
-    def head(t, key):                                                          # netR_FC (:201-207), two BN calls (:228-229)
-        y = t @ q["netR_FC.0.weight"].t() + q["netR_FC.0.bias"]
-        a = torch.relu(_bn_train64(y, q["netR_FC.1.weight"], q["netR_FC.1.bias"], stats, key))
-        return a @ q["netR_FC.3.weight"].t() + q["netR_FC.3.bias"]
-    x = head(x_pre, "fc_a")
-    xg = head(xg_pre, "fc_b")
-    return x, xg, stats, q
 
 
 # prec "x3" / "x3b": the opt-in three-product arithmetic (facl_amd.tail.precision).  "x3b" (backward GEMMs only) must
@@ -89,9 +47,11 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D, prec):
     # outputs of the step's own forward: hook the model call
     taps = {}
     h = net.register_forward_hook(lambda m, i, o: taps.update(x=o[0].detach().clone(), xg=o[3].detach().clone()))
-    loss, loss_c, loss_circle = step(clip, epoch=0, order=order)
+    with routing_taps() as routing:                      # argmax tensors of the three max-pools (tie-proof gradient check below)
+        loss, loss_c, loss_circle = step(clip, epoch=0, order=order)
     h.remove()
     torch.cuda.synchronize()
+    grads = {k: p.grad.detach().double().clone() for k, p in net.named_parameters() if p.grad is not None}
 
     # ---- fp64 truth on the same grouped input (the grouping itself is bit-exact integer work: tests/test_gpu_grouping.py)
     data1 = clip.permute(1, 0, 2, 3).reshape(-1, N, D).float()
@@ -99,7 +59,7 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D, prec):
     x_rows = xt.permute(0, 2, 3, 1).reshape(-1, D)
     centers = yt.permute(0, 2, 1, 3).reshape(-1, 3)
     with torch.no_grad():
-        x64, xg64, stats, q = _forward64(x_rows, centers, sd, G, S, K)
+        x64, xg64, stats, q, _ = forward64(x_rows, centers, sd, G, S, K, DEV)
         lc64 = float(OL.global_contrast(G, xg64, x64, B))                      # the reference's literal logits construction
         lo64 = float(OL.circle_contrast(G, x64, B, order))
     e_x = max_rel_rows(taps["x"].cpu().numpy(), x64.cpu().numpy())
@@ -131,3 +91,32 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D, prec):
     for k, p in net.named_parameters():
         d = (p.detach().cpu().double() - torch.as_tensor(sd[k]).double()).abs().max().item()
         assert d <= 2 * 3e-4, (k, d)
+    # ---- end-to-end gradients at the headline size (default arithmetic), tie-proof: the fp64 graph routes its three max-pools
+    # through the positions the HIP forward chose (each verified to be a numerical tie of the fp64 values)
+    if prec != "f32":
+        return
+    del x64, xg64
+
+    def routed(dtype):
+        x_, xg_, _, q_, ties_ = forward64(x_rows, centers, sd, G, S, K, DEV, routing=routing, grad=True, dtype=dtype)
+        (OL.global_contrast(G, xg_, x_, B) + OL.circle_contrast(G, x_, B, order)).backward()
+        return {k: q_[k].grad.double() for k in grads if q_[k].grad is not None}, ties_
+    g64, ties = routed(torch.float64)
+    g32, _ = routed(torch.float32)                       # plain torch fp32, same routing: the conditioning yardstick
+    print("ties", ties)
+    assert max(ties["sa"], ties["seg"], ties["view"]) < 1e-5, ties
+    pre_bn_bias = {"net3DV_1.0.bias", "net3DV_1.3.bias", "net3DV_1.6.bias", "net3DV_3.0.bias", "net3DV_3.3.bias",
+                   "net3DV_3.6.bias", "netR_FC.0.bias", "net3DV_3.7.bias"}              # mathematically zero gradients
+    gmax = max(float(g64[k].norm()) for k in g64)
+    bad = []
+    for k, mine in grads.items():
+        if k in pre_bn_bias or k not in g64:
+            continue
+        r = g64[k].reshape(mine.shape)
+        err, e32 = float((mine - r).norm()), float((g32[k].reshape(mine.shape) - r).norm())
+        print(f"grad {k:20s} vs routed fp64: {err / float(r.norm()):.2e}   torch-fp32 (same routing) {e32 / float(r.norm()):.2e}  (|g| {float(r.norm()):.2e})")
+        # 1e-4 of the tensor's gradient norm, or the distance of torch's own fp32 autograd of the same routed graph where
+        # the quantity is ill-conditioned at this size (BatchNorm backward: differences of sums over 3.1 M positions)
+        if err > max(1e-4 * max(float(r.norm()), 1e-2 * gmax), e32):
+            bad.append((k, err, e32, float(r.norm())))
+    assert not bad, bad

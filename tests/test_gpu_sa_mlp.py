@@ -106,7 +106,9 @@ def test_sa_backward_vs_oracle_fp64(D, neg):
     up = up * (torch.rand(up.shape, generator=torch.Generator().manual_seed(2)).to(DEV) > 0.3)   # some exact zeros
     (pooled * up).sum().backward()
 
-    def ref(dtype):
+    arg = pooled.grad_fn.c["arg"].cpu().long()                  # (M*S, 256): the position the HIP forward's max-pool chose
+
+    def ref(dtype, routed=False):
         sdr = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v).clone())
                for k, v in sd.items()}
         keys = [k for k in sdr if k.startswith("net3DV_1") and "running" not in k and "num_batches" not in k]
@@ -115,11 +117,21 @@ def test_sa_backward_vs_oracle_fp64(D, neg):
         h = xt.cpu().to(dtype)
         for li in (0, 3, 6):
             h = E._conv_bn_relu(sdr, "net3DV_1", li, h, True)
-        pl = F.max_pool2d(h, (1, K), stride=1).squeeze(-1).permute(0, 2, 1).reshape(-1, 256)
+        mx = F.max_pool2d(h, (1, K), stride=1)                   # (M,256,S,1)
+        tie = 0.0
+        if routed:
+            # tie-proof: route the gradient through the KERNEL's argmax (a gather) instead of this arithmetic's own; every
+            # decision that differs must be a numerical tie -- the gathered value equals the fp64 maximum to 1e-5
+            got = torch.gather(h, 3, arg.view(M, S, 256).permute(0, 2, 1).unsqueeze(-1))
+            tie = float(((mx - got).abs() / torch.maximum(mx.abs(), h.abs().mean())).max())
+            mx = got
+        pl = mx.squeeze(-1).permute(0, 2, 1).reshape(-1, 256)
         (pl * up.cpu().to(dtype)).sum().backward()
-        return {k: sdr[k].grad for k in keys}
+        return {k: sdr[k].grad for k in keys}, tie
 
-    g64, g32 = ref(torch.float64), ref(torch.float32)
+    (g64r, tie), (g64, _), (g32, _) = ref(torch.float64, True), ref(torch.float64), ref(torch.float32)
+    print(f"largest distance of a kernel-chosen position from the fp64 maximum: {tie:.2e}")
+    assert tie < 1e-5
     keymap = {"W1": "net3DV_1.0.weight", "b1": "net3DV_1.0.bias", "g1": "net3DV_1.1.weight", "be1": "net3DV_1.1.bias",
               "W2": "net3DV_1.3.weight", "b2": "net3DV_1.3.bias", "g2": "net3DV_1.4.weight", "be2": "net3DV_1.4.bias",
               "W3": "net3DV_1.6.weight", "b3": "net3DV_1.6.bias", "g3": "net3DV_1.7.weight", "be3": "net3DV_1.7.bias"}
@@ -129,12 +141,15 @@ def test_sa_backward_vs_oracle_fp64(D, neg):
         if k in ("b1", "b2", "b3"):                    # mathematically zero (bias before a train-mode BN)
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
             continue
+        e_routed = rel_err(mine, g64r[keymap[k]].numpy())
         e_mine = rel_err(mine, r64)
         e_t32 = rel_err(g32[keymap[k]].numpy(), r64)
-        print(f"{k}: mine-vs-fp64 {e_mine:.2e}  torch-fp32-vs-fp64 {e_t32:.2e}")
-        # Near-ties of the max-pool: where torch's own fp32 run routes a gradient to a different (numerically tied) position
-        # than the fp64 run does, it sits 3e-3..1e-2 from fp64 on every parameter; an fp32-grade kernel may land on either side
-        # of such a tie (which side depends on its rounding, e.g. bf16x6 vs fp16x3), so there the bar is the reference's own distance.
+        print(f"{k}: vs routed fp64 {e_routed:.2e}   vs plain fp64 {e_mine:.2e}  torch-fp32-vs-fp64 {e_t32:.2e}")
+        # THE bound: with the max-pool routing pinned to the kernel's own (verified-tie) decisions the
+        # comparison is pure arithmetic -- 1e-4 per parameter, measured 2e-7 .. 3e-6
+        assert e_routed < 1e-4, k
+        # second, looser check against the un-routed fp64 graph: where torch's own fp32 run lands on the other side of a
+        # near-tie than fp64 does it sits 3e-3..1e-2 away on every parameter, and an fp32-grade kernel may land on either side
         assert e_mine < max(1e-4, 1.5 * e_t32), k
         assert e_mine < 3 * e_t32 + 1e-5, k
 
@@ -205,43 +220,65 @@ def test_sa_headline_size_forward_backward_vs_torch_fp64():
     w = torch.randn(pooled.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     (pooled * w).sum().backward()
 
-    # ---- fp64 reference, layer by layer (frees each activation's fp32 twin: ~20 GB peak)
-    q = {k: p64.detach().double().requires_grad_(True) for k, p64 in zip(sa_mlp._PARAM_ORDER, [p[k] for k in sa_mlp._PARAM_ORDER])}
-    h = x_rows.double()
-    P = h.shape[0]
-    stats = []
-    for li, (Wk, bk, gk, bek) in enumerate((("W1", "b1", "g1", "be1"), ("W2", "b2", "g2", "be2"), ("W3", "b3", "g3", "be3"))):
-        y = h @ q[Wk].reshape(q[Wk].shape[0], -1).t() + q[bk]
-        mean, var = y.mean(0), y.var(0, unbiased=False)
-        stats.append((mean.detach(), (var * P / (P - 1)).detach()))
-        h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * q[gk] + q[bek])
-        del y
-    ref, ref_arg = h.view(M * S, K, 256).max(dim=1)
-    del h
-    # the max-pool decisions themselves: bit-exact argmax except where two neighbours are within fp32 rounding
+    # ---- fp64 reference, layer by layer, plus its fp32 twin (plain torch ops, same graph): the conditioning yardstick
     my_arg = pooled.grad_fn.c["arg"].long()
-    flips = int((my_arg != ref_arg).sum())
-    print(f"argmax decisions {ref_arg.numel()}, fp32-vs-fp64 flips {flips}")
-    assert flips < 1e-4 * ref_arg.numel()        # measured 436 of 12.6 M (y3 carries ~1e-6 relative fp32 noise)
-    assert max_rel_rows(pooled.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-5
-    (ref * w.double()).sum().backward()
+
+    def ref(dtype):
+        q = {k: p[k].detach().to(dtype).requires_grad_(True) for k in sa_mlp._PARAM_ORDER}
+        h = x_rows.to(dtype)
+        P = h.shape[0]
+        stats = []
+        for li, (Wk, bk, gk, bek) in enumerate((("W1", "b1", "g1", "be1"), ("W2", "b2", "g2", "be2"), ("W3", "b3", "g3", "be3"))):
+            y = h @ q[Wk].reshape(q[Wk].shape[0], -1).t() + q[bk]
+            mean, var = y.mean(0), y.var(0, unbiased=False)
+            stats.append((mean.detach(), (var * P / (P - 1)).detach()))
+            h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * q[gk] + q[bek])
+            del y
+        h3 = h.view(M * S, K, 256)
+        mx, mx_arg = h3.max(dim=1)
+        # tie-proof backward: the graph routes its gradient through the KERNEL's argmax; every differing
+        # decision must be a numerical tie (gathered value == the maximum to 1e-5 of the activation scale)
+        got = torch.gather(h3, 1, my_arg.unsqueeze(1)).squeeze(1)
+        tie = float(((mx - got).abs() / torch.maximum(mx.abs(), h3.detach().abs().mean())).max())
+        flips = int((my_arg != mx_arg).sum())
+        out = mx.detach().clone()
+        del h, h3, mx
+        (got * w.to(dtype)).sum().backward()
+        return q, stats, out, tie, flips
+
+    q, stats, ref64, tie, flips = ref(torch.float64)
+    # the max-pool decisions themselves: bit-exact argmax except where two neighbours are within fp32 rounding
+    print(f"argmax decisions {my_arg.numel()}, fp32-vs-fp64 flips {flips}; largest distance of a kernel-chosen position "
+          f"from the fp64 maximum: {tie:.2e}")
+    assert flips < 1e-4 * my_arg.numel()        # measured 436 of 12.6 M (y3 carries ~1e-6 relative fp32 noise)
+    assert tie < 1e-5
+    assert max_rel_rows(pooled.detach().cpu().numpy(), ref64.cpu().numpy()) < 2e-5
     for i, (mean, uvar) in enumerate(stats, 1):                                    # momentum 0.1 from (0, 1)
         sd0m, sd0v = torch.as_tensor(sd[f"net3DV_1.{3 * i - 2}.running_mean"]).double().to(DEV), \
             torch.as_tensor(sd[f"net3DV_1.{3 * i - 2}.running_var"]).double().to(DEV)
         assert rel_err(p[f"rm{i}"].cpu().numpy(), (0.9 * sd0m + 0.1 * mean).cpu().numpy()) < 5e-6, i
         assert rel_err(p[f"rv{i}"].cpu().numpy(), (0.9 * sd0v + 0.1 * uvar).cpu().numpy()) < 5e-6, i
-    gmax = max(float(q[k].grad.norm()) for k in q)
+    g64 = {k: q[k].grad.clone() for k in q}
+    del q, stats, ref64
+    q32 = ref(torch.float32)[0]
+    gmax = max(float(g64[k].norm()) for k in g64)
+    bad = []
     for k, mine in zip(sa_mlp._PARAM_ORDER, params):
-        g64 = q[k].grad
         if k in ("b1", "b2", "b3"):
             # a conv bias in front of a train-mode BN has a mathematically zero gradient (returned as None)
-            assert mine.grad is None and float(g64.norm()) < 1e-6 * gmax, k
+            assert mine.grad is None and float(g64[k].norm()) < 1e-6 * gmax, k
             continue
-        err = float((mine.grad.double() - g64).norm())
-        print(f"{k:4s} |g| {float(g64.norm()):.3e}  err {err:.3e}  rel {err / float(g64.norm()):.2e}")
-        # ~50M max-pool decisions at this size: the handful of fp32-vs-fp64 near-tie flips put a floor of ~2e-3 of the
-        # layer's gradient norm on the comparison (the kernel-level tests at small sizes hold 1e-5)
-        assert err <= 5e-3 * max(float(g64.norm()), 1e-2 * gmax), (k, err, float(g64.norm()))
+        err = float((mine.grad.double() - g64[k]).norm())
+        e32 = float((q32[k].grad.double() - g64[k]).norm())
+        print(f"{k:4s} |g| {float(g64[k].norm()):.3e}  mine-vs-routed-fp64 {err / float(g64[k].norm()):.2e}   "
+              f"torch-fp32 (same routing) {e32 / float(g64[k].norm()):.2e}")
+        # With the routing pinned to the kernel's (verified-tie) decisions the comparison is pure arithmetic.  1e-4 of the
+        # tensor's gradient norm, OR -- where the quantity itself is ill-conditioned at 3.1 M positions (train-mode BN's
+        # backward subtracts two sums over all positions: torch's own fp32 autograd of the same routed graph sits that far
+        # from fp64) -- the distance of that fp32 twin
+        if err > max(1e-4 * max(float(g64[k].norm()), 1e-2 * gmax), 1.0 * e32):
+            bad.append((k, err, e32, float(g64[k].norm())))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("nunits", [1, 3, 5, 7, 1021, 1026])
@@ -266,14 +303,18 @@ def test_sa_ragged_unit_counts(nunits):
         y = h @ q[Wk].reshape(q[Wk].shape[0], -1).t() + q[bk]
         mean, var = y.mean(0), y.var(0, unbiased=False)
         h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * q[gk] + q[bek])
-    ref, ref_arg = h.view(nunits, K, 256).max(dim=1)
+    h3 = h.view(nunits, K, 256)
+    ref, ref_arg = h3.max(dim=1)
     assert max_rel_rows(pooled.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 5e-5
-    (ref * w.double()).sum().backward()
-    # a max-pool decision that differs from fp64 (two neighbours within fp32 rounding) re-routes a whole gradient row:
-    # without such flips the gradients must agree tightly, with them only to the flip floor
-    flips = int((pooled.grad_fn.c["arg"].long() != ref_arg).sum())
+    # a max-pool decision that differs from fp64 (two neighbours within fp32 rounding) re-routes a whole gradient row: the
+    # fp64 graph is routed through the kernel's decisions (each verified to be a tie), so flips no longer loosen the bound
+    my_arg = pooled.grad_fn.c["arg"].long()
+    flips = int((my_arg != ref_arg).sum())
     assert flips <= max(2, 1e-4 * ref_arg.numel())
-    tol = 2e-3 if flips == 0 else 2e-2
+    got = torch.gather(h3, 1, my_arg.unsqueeze(1)).squeeze(1)
+    assert float(((ref - got).abs() / torch.maximum(ref.abs(), h3.detach().abs().mean())).max()) < 1e-5
+    (got * w.double()).sum().backward()
+    tol = 2e-3
     gmax = max(float(q[k].grad.norm()) for k in q)
     for k, mine in zip(sa_mlp._PARAM_ORDER, params):
         if k in ("b1", "b2", "b3"):

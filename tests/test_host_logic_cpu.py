@@ -161,6 +161,73 @@ def test_world_size_2_gloo_sharded_loss_equals_global():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+# ---- failure protocol of the segmented graph capture (facl_amd/dist.py: GraphSegments votes), 2 gloo ranks, no GPU ----
+def _worker_capture_protocol(rank, world, port, q, fail_rank, fail_cut, ncoll):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      FACL_DIST_BACKEND="gloo", FACL_DIST_TIMEOUT_S="30")
+    if fail_rank is not None:
+        os.environ["FACL_TEST_CAPTURE_FAIL"] = "%d:%d" % (fail_rank, fail_cut)
+    import torch.distributed as dist
+    from facl_amd import dist as fdist
+    fdist.init_from_env()
+
+    class FakeSegments(fdist.GraphSegments):             # the protocol without a device: "graphs" are plain markers
+        def __init__(self):
+            self.pool, self.items, self.cur, self.ncuts = None, [], None, 0
+            self.voting = True
+            self._inject = {}
+            v = os.environ.get("FACL_TEST_CAPTURE_FAIL")
+            if v and int(v.split(":")[0]) == dist.get_rank():
+                self._inject["FACL_TEST_CAPTURE_FAIL"] = int(v.split(":")[1])
+
+        def begin(self):
+            self.cur = "graph"
+
+        def _close(self):
+            self.items.append(self.cur)
+            self.cur = None
+
+        def abort(self):
+            self.cur = None
+
+    t = torch.zeros(1, dtype=torch.float64)
+
+    def body():
+        for i in range(ncoll):
+            fdist.collective(lambda: dist.all_reduce(t.fill_(1.0)))
+        return "captured"
+
+    rec = FakeSegments()
+    try:
+        out = fdist.run_capture(rec, body, rank)
+    except fdist.CaptureFailed as e:
+        out = "failed: " + str(e)
+    # whatever happened, the ranks are at the SAME point of the collective sequence: an eager collective completes at once
+    dist.all_reduce(t.fill_(float(rank + 1)))
+    q.put((rank, out.split(":")[0], rec.ncuts, float(t)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank,fail_cut,ncoll", [(None, 0, 5), (1, 3, 5), (0, 0, 5), (1, 4, 5)])
+def test_capture_failure_on_one_rank_is_agreed_on_by_all_ranks(fail_rank, fail_cut, ncoll):
+    """a capture that fails on ONE rank after k collectives must take EVERY rank out of the capture at the same
+    collective (then all continue eagerly together) -- never one rank eager against others replaying."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 2000) + (0 if fail_rank is None else 7 * (fail_rank + 1) + fail_cut)
+    procs = [ctx.Process(target=_worker_capture_protocol, args=(r, 2, port, q, fail_rank, fail_cut, ncoll)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    expect = "captured" if fail_rank is None else "failed"
+    assert [r[1] for r in res] == [expect, expect], res
+    assert res[0][2] == res[1][2] == (ncoll if fail_rank is None else fail_cut), res     # same number of collectives issued
+    assert res[0][3] == res[1][3] == 3.0, res                                           # and the next eager one pairs up
+
+
 # ---- the embeddings exchange with R simulated ranks (lists of tensors): layout math of BOTH backward branches ----
 @pytest.mark.parametrize("R", [2, 4, 8])
 def test_simulated_ranks_reduce_scatter_layout_equals_allreduce_slice_and_single_process(R):

@@ -201,6 +201,14 @@ def tap(name, t):
         TAPS[name] = t.detach().clone()
 
 
+def tap_relu(name, y=None, scale=None, shift=None, a=None):
+    """ReLU decisions of a layer as a bool tensor: `a > 0` where the activation exists, else the sign of the kernels' own
+    fma(scale, y, shift) (BatchNorm folded into two constants per channel) evaluated exactly: the product of two fp32
+    numbers and the sum are exact enough in fp64 that the sign equals the sign of the fp32 FMA."""
+    if TAPS is not None:
+        TAPS[name] = (a > 0) if a is not None else ((y.double() * scale.double() + shift.double()) > 0)
+
+
 # ---- optional in-step kernel timing (bench.py's roofline section) ----------------------------------------------------
 # When TIMING is a dict, `timed(label)` brackets the launches issued inside the `with` block with HIP events on the
 # launch stream (eager execution only: events cannot be recorded inside a graph replay) and appends the event pair to

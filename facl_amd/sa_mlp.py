@@ -165,6 +165,15 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     pooled = _lib.empty((ngroups, 256), dtype=torch.float32, device=dev)
     _lib.check(lib.facl_sa_pool(_lib.ptr(ymax_g), ngroups, 256, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(pooled), st),
                "facl_sa_pool")
+    if _lib.TAPS is not None and K == UNIT:          # tests only: the ReLU decisions of the three layers (tie-proof parity)
+        xd, tb = x_rows.double(), l1tab.double()
+        v = (tb[:, 0] * xd[:, :1] + tb[:, 4]).float().double()                # the kernels' sequential fp32 FMA chain
+        for i in range(1, D):
+            v = (tb[:, i] * xd[:, i:i + 1] + v).float().double()
+        _lib.TAPS["relu_sa1"] = v > 0
+        y2n = y2f.view(nunits, 2, 2, 4, 2, 32, 4).permute(0, 1, 5, 2, 3, 4, 6).reshape(nunits * UNIT, 64)   # fragment layout -> (P, 64)
+        _lib.tap_relu("relu_sa2", y2n, bnc2[2], bnc2[3])
+        _lib.tap_relu("relu_sa3", a=pooled)
     ctx.update(y2f=y2f, ymax=ymax_g, arg=arg, bnc1=bnc1, bnc2=bnc2, bnc3=bnc3, sgn3=sgn3, l1tab=l1tab, count=count,
                nunits=nunits, D=D, R=R, rsel=rsel, ngroups=ngroups, x_rows=x_rows)
     return pooled, ctx

@@ -174,6 +174,7 @@ class _LinearBNReLU(torch.autograd.Function):
         a = _lib.empty_like(y)
         _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y), R, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(a),
                                          _lib.stream()), "facl_rows_bn_relu")
+        _lib.tap_relu("relu_t%d" % (1 if centers is not None else 2), a=a)
         ctx.save_for_backward(h, W, y, bnc)
         ctx.count, ctx.reduce_fn, ctx.training = count, reduce_fn, training
         return a
@@ -246,6 +247,7 @@ class _LinearBNSegmax(torch.autograd.Function):
             _lib.check(lib.facl_rows_segmax(_lib.ptr(y), M, S, C, _lib.ptr(bnc), _lib.ptr(xpre), _lib.ptr(arg),
                                             _lib.stream()), "facl_rows_segmax")
         _lib.tap("seg_arg", arg)
+        _lib.tap_relu("relu_t3", a=xpre)
         ctx.save_for_backward(h, W, y, bnc, xpre, arg)
         ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
         ctx.mark_non_differentiable(arg)
@@ -356,6 +358,7 @@ class _FCHead(torch.autograd.Function):
                                              _lib.ptr(a[r0:r1]), _lib.stream()), "facl_rows_bn_relu")
             bncs.append(bnc)
             counts.append(count)
+        _lib.tap_relu("relu_fc", a=a)
         out, _ = gemm_fwd(a, W2, b2, prec=ctx.prec)
         ctx.save_for_backward(h, W1, y, a, W2, arg, *bncs)
         ctx.segs, ctx.counts, ctx.reduce_fn, ctx.training, ctx.G = segs, counts, reduce_fn, training, G
@@ -662,6 +665,9 @@ class _Net3DV3(torch.autograd.Function):
         _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(xpre), _lib.stream()),
                    "facl_sa_pool")
         _lib.tap("seg_arg", arg)
+        _lib.tap_relu("relu_t1", y1, bnc1[2], bnc1[3])
+        _lib.tap_relu("relu_t2", y2, bnc2[2], bnc2[3])
+        _lib.tap_relu("relu_t3", a=xpre)
         ctx.save_for_backward(pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg)
         ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
         return xpre

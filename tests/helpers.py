@@ -93,32 +93,56 @@ def forward64(x_rows, centers, sd, G, S, K, dev, routing=None, grad=False, dtype
         return got
 
     r = routing or {}
+
+    def relu(z, name):
+        """ReLU, or -- with the kernel's own decisions in `routing` -- z * mask.  Every decision that differs from z > 0 must
+        be a numerical tie: |z| there <= 1e-5 of the layer's mean |z| (recorded in ties["relu_*"])."""
+        mask = r.get(name)
+        if mask is None:
+            return torch.relu(z)
+        with torch.no_grad():
+            diff = mask.view(z.shape) != (z > 0)
+            ties[name + "_flips"] = int(diff.sum())
+            ties[name] = float((z.abs() * diff).max() / z.abs().mean())
+        return z * mask.view(z.shape)
+
     h = x_rows.to(dtype)
-    for li in (0, 3, 6):                                                       # net3DV_1 (:43-58)
+    for i, li in enumerate((0, 3, 6)):                                         # net3DV_1 (:43-58)
         W = q[f"net3DV_1.{li}.weight"].reshape(q[f"net3DV_1.{li}.weight"].shape[0], -1)
         y = h @ W.t() + q[f"net3DV_1.{li}.bias"]
-        h = torch.relu(bn_train(y, q[f"net3DV_1.{li + 1}.weight"], q[f"net3DV_1.{li + 1}.bias"], f"net3DV_1.{li + 1}"))
+        z = bn_train(y, q[f"net3DV_1.{li + 1}.weight"], q[f"net3DV_1.{li + 1}.bias"], f"net3DV_1.{li + 1}")
         del y
+        # the third layer's ReLU sits behind the max-pool in the kernels (monotone per channel): its decision is pinned there
+        h = relu(z, f"relu_sa{i + 1}") if i < 2 else z
+        del z
     MS = h.shape[0] // K
     pooled = pool(h.view(MS, K, 256), r.get("sa_arg"), "sa")
     del h
+    pooled = relu(pooled, "relu_sa3")
     h = torch.cat((centers.to(dtype), pooled), dim=1)                           # :219
-    for li in (0, 3, 6):                                                       # net3DV_3 (:61-77)
+    for i, li in enumerate((0, 3, 6)):                                         # net3DV_3 (:61-77)
         W = q[f"net3DV_3.{li}.weight"].reshape(q[f"net3DV_3.{li}.weight"].shape[0], -1)
         y = h @ W.t() + q[f"net3DV_3.{li}.bias"]
-        h = torch.relu(bn_train(y, q[f"net3DV_3.{li + 1}.weight"], q[f"net3DV_3.{li + 1}.bias"], f"net3DV_3.{li + 1}"))
+        z = bn_train(y, q[f"net3DV_3.{li + 1}.weight"], q[f"net3DV_3.{li + 1}.bias"], f"net3DV_3.{li + 1}")
+        h = relu(z, f"relu_t{i + 1}") if i < 2 else z
     M = MS // S
     B = M // G
-    x_pre = pool(h.view(M, S, 1024), r.get("seg_arg"), "seg")                  # :222
+    x_pre = relu(pool(h.view(M, S, 1024), r.get("seg_arg"), "seg"), "relu_t3")   # :222 (max of relu = relu of max)
     # :225-226 (rows are view-major g*B+b): max over all G*S local features of a clip = max over the views of the view maxima
     xg_pre = pool(x_pre.view(G, B, 1024).transpose(0, 1), r.get("view_arg"), "view")
 
-    def head(t, key):                                                          # netR_FC (:201-207), two BN calls (:228-229)
+    fcm = r.get("relu_fc")                                                     # (M + B, 1024): view rows, then clip rows
+
+    def head(t, key, mask):                                                    # netR_FC (:201-207), two BN calls (:228-229)
         y = t @ q["netR_FC.0.weight"].t() + q["netR_FC.0.bias"]
-        a = torch.relu(bn_train(y, q["netR_FC.1.weight"], q["netR_FC.1.bias"], key))
+        z = bn_train(y, q["netR_FC.1.weight"], q["netR_FC.1.bias"], key)
+        if mask is not None:
+            r["relu_" + key] = mask
+        a = relu(z, "relu_" + key)
         return a @ q["netR_FC.3.weight"].t() + q["netR_FC.3.bias"]
-    x = head(x_pre, "fc_a")
-    xg = head(xg_pre, "fc_b")
+    r = dict(r)
+    x = head(x_pre, "fc_a", None if fcm is None else fcm[:M])
+    xg = head(xg_pre, "fc_b", None if fcm is None else fcm[M:])
     return x, xg, stats, q, ties
 
 

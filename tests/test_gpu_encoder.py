@@ -141,9 +141,10 @@ def test_c1_golden_forward_loss_backward_adam(tag, D, neg):
                 # 2e-4 on the GPU box's CPU, 7e-3 in the build container for the SAME oracle code.  The
                 # kernel-level gradient check (same upstream gradient, no flips) is test_gpu_sa_mlp.py: 3e-7.
                 assert e_mine <= max(3 * e_t32, 5e-3), k
-            # THE gradient bound: fp64 evaluation of the same graph on the same grouped rows, its three
-            # max-pools routed through the positions the HIP forward chose (each verified to be a tie of the fp64 values), so
-            # the comparison is pure arithmetic: every parameter tensor within 1e-4 (of its norm, floored at 1 % of the largest)
+            # THE gradient bound: fp64 evaluation of the same graph on the same grouped rows with every DISCRETE
+            # decision pinned to the one the HIP forward took -- the three max-pools gather at its argmax, the ReLUs keep
+            # the elements it kept (each differing decision verified to be a numerical tie of the fp64 values) -- so the
+            # comparison is pure arithmetic: every parameter tensor within 1e-4 (of its norm, floored at 1 % of the largest)
             from oracle import loss as OL
             from oracle.weights import formula_state_dict
             xr, cr = xt.permute(0, 2, 3, 1).reshape(-1, D), yt.permute(0, 2, 1, 3).reshape(-1, 3)
@@ -155,7 +156,7 @@ def test_c1_golden_forward_loss_backward_adam(tag, D, neg):
             q64, ties = routed(torch.float64)
             q32, _ = routed(torch.float32)               # plain torch fp32, same routing: the conditioning yardstick
             print("ties", ties)
-            assert max(ties["sa"], ties["seg"], ties["view"]) < 1e-5, ties
+            assert max(v for k, v in ties.items() if not k.endswith("_flips")) < 1e-5, ties   # every differing decision was a tie
             gmax64 = max(float(q64[k].grad.norm()) for k, _ in net.named_parameters() if q64[k].grad is not None)
             for k, p in net.named_parameters():
                 if k in PRE_BN_BIAS or q64[k].grad is None or k == "net3DV_3.7.bias":   # mathematically ~0 gradients
@@ -164,9 +165,7 @@ def test_c1_golden_forward_loss_backward_adam(tag, D, neg):
                 err = float((p.grad.double() - r).norm())
                 e32 = float((q32[k].grad.reshape(p.shape).double() - r).norm())
                 print(f"grad {k:20s} vs routed fp64: {err / float(r.norm()):.2e}   torch-fp32 (same routing) {e32 / float(r.norm()):.2e}")
-                # 1e-4, or the distance of torch's own fp32 autograd of the same routed graph where the quantity is
-                # ill-conditioned (train-mode BatchNorm over B = 4 rows in netR_FC's second call)
-                assert err <= max(1e-4 * max(float(r.norm()), 1e-2 * gmax64), e32), (k, err, e32, float(r.norm()))
+                assert err <= 1e-4 * max(float(r.norm()), 1e-2 * gmax64), (k, err, e32, float(r.norm()))
             sd = net.state_dict()
             for k in sd:
                 if "running_" in k:

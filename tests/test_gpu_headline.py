@@ -104,7 +104,7 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D, prec):
     g64, ties = routed(torch.float64)
     g32, _ = routed(torch.float32)                       # plain torch fp32, same routing: the conditioning yardstick
     print("ties", ties)
-    assert max(ties["sa"], ties["seg"], ties["view"]) < 1e-5, ties
+    assert max(v for k, v in ties.items() if not k.endswith("_flips")) < 1e-5, ties   # every differing decision was a tie
     pre_bn_bias = {"net3DV_1.0.bias", "net3DV_1.3.bias", "net3DV_1.6.bias", "net3DV_3.0.bias", "net3DV_3.3.bias",
                    "net3DV_3.6.bias", "netR_FC.0.bias", "net3DV_3.7.bias"}              # mathematically zero gradients
     gmax = max(float(g64[k].norm()) for k in g64)
@@ -115,8 +115,7 @@ def test_full_step_at_headline_size_vs_torch_fp64(stream, D, prec):
         r = g64[k].reshape(mine.shape)
         err, e32 = float((mine - r).norm()), float((g32[k].reshape(mine.shape) - r).norm())
         print(f"grad {k:20s} vs routed fp64: {err / float(r.norm()):.2e}   torch-fp32 (same routing) {e32 / float(r.norm()):.2e}  (|g| {float(r.norm()):.2e})")
-        # 1e-4 of the tensor's gradient norm, or the distance of torch's own fp32 autograd of the same routed graph where
-        # the quantity is ill-conditioned at this size (BatchNorm backward: differences of sums over 3.1 M positions)
-        if err > max(1e-4 * max(float(r.norm()), 1e-2 * gmax), e32):
+        # every discrete decision pinned (max-pool argmax, ReLU signs): 1e-4 of the tensor's gradient norm
+        if err > 1e-4 * max(float(r.norm()), 1e-2 * gmax):
             bad.append((k, err, e32, float(r.norm())))
     assert not bad, bad

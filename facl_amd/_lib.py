@@ -35,16 +35,18 @@ SIGNATURES = {
     "facl_adam_prep": [c_p, c_p, c_f, c_f, c_p, c_p],
     "facl_adam_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p],
     "facl_ws_bytes": [],
-    "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],
+    "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p],
+    "facl_absmax": [c_p, c_l, c_p, c_p],
+    "facl_rows_act_amax": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],
     "facl_sa_x_moments": [c_p, c_l, c_i, c_p, c_p, c_p],
     "facl_bn1_sums_from_moments": [c_p, c_d, c_i, c_p, c_p, c_p, c_p],
-    "facl_sa_l1tab": [c_p, c_p, c_i, c_p, c_p, c_p, c_p],
-    "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_l1tab": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    "facl_sa_fwd3_h3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_fwd3_h3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3_f16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_rows_stats": [c_p, c_l, c_i, c_p, c_p, c_p],
     "facl_rows_bn_relu": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_segmax": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
@@ -64,14 +66,14 @@ SIGNATURES = {
     "facl_gemm_wgrad_f16": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "facl_gemm_wgrad_pro": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_gemm_wgrad_pro_x3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
-    "facl_gemm_wgrad_h3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
+    "facl_gemm_wgrad_h3": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_gemm_rs_wgrad_slices": [c_l, c_i, c_i],
-    "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_planes_bytes": [c_i, c_i, c_i],
     "facl_gemm_rs_planes": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "facl_gemm_rs_planes_multi": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_supported": [c_l, c_i, c_i],
-    "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p],
     "facl_gemm_rs_dgrad_bnstats": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd_x3": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
@@ -86,9 +88,9 @@ SIGNATURES = {
     "facl_build_views_f32": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "facl_build_views_f64": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "facl_sa_bwd0": [c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
-    "facl_sa_bwd1": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    "facl_sa_bwd_w3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p],
-    "facl_sa_bwd2": [c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd1": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd_w3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_bwd2": [c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_bwd_consts3": [c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p],
     "facl_sa_bwd_consts2": [c_p, c_p, c_d, c_p, c_p],
     "facl_bn_bwd_consts": [c_p, c_p, c_i, c_d, c_p, c_p, c_p, c_p],
@@ -135,6 +137,13 @@ def check(rc, what):
 
 
 AMAX_WORDS = 2048          # include/facl_hip.h: FACL_AMAX_WORDS
+
+
+def amax_buffers(n, device):
+    """(n, AMAX_WORDS) int32 zeros: n operand-maximum buffers of the fp16x3 GEMMs (csrc/common.h).  Producers either store a
+    bound into every slot (facl_bn_finalize) or RAISE slots with atomics (facl_sa_pool, facl_absmax, the BatchNorm-backward
+    row kernels), which is why they start from zero."""
+    return torch.zeros((n, AMAX_WORDS), dtype=torch.int32, device=device)
 
 
 def ptr(t):

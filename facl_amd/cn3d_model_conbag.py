@@ -157,9 +157,9 @@ class PointNet_Plus(nn.Module):
             for i in (1, 4, 7):
                 self.net3DV_1[i].count_batch()
         with _tail.precision(prec):
-            return self._tail_forward(pooled, centers, M, S, training)
+            return self._tail_forward(pooled, centers, M, S, training, state.get("pooled_amax"))
 
-    def _tail_forward(self, pooled, centers, M, S, training):
+    def _tail_forward(self, pooled, centers, M, S, training, pooled_amax=None):
 
         # net3DV_3 (:220).  torch.cat((yt, xt), 1) (:219) is never built: the first GEMM takes the centroid xyz as a
         # rank-3 term in its epilogue
@@ -167,7 +167,7 @@ class PointNet_Plus(nn.Module):
         widths = (n3[0].weight.shape[1] - 3, n3[0].weight.shape[0], n3[3].weight.shape[0], n3[6].weight.shape[0])
         if _tail.net3dv3_supported(pooled.shape[0], widths, S, _tail.current_precision()):
             # the 49,152-row case: row-streamed GEMMs, BN + ReLU of a layer applied in the next GEMM's prologue
-            x_pre = _tail.net3dv3(pooled, centers, n3, training, S, self.bn_reduce_fn)
+            x_pre = _tail.net3dv3(pooled, centers, n3, training, S, self.bn_reduce_fn, pooled_amax)
         else:
             h = _tail.linear_bn_relu(pooled, n3[0], n3[1], training, self.bn_reduce_fn, centers=centers)
             h = _tail.linear_bn_relu(h, n3[3], n3[4], training, self.bn_reduce_fn)

@@ -17,6 +17,13 @@ __device__ __forceinline__ float sgn_of(float g) { return g < 0.f ? -1.f : 1.f; 
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// ReLU that keeps NaN (torch.relu / nn.ReLU do; fmaxf(NaN, 0) = 0 would turn a poisoned activation into a clean zero):
+// max(x, 0) + 0 * x -- the product is (+-)0 for every finite x and NaN for NaN (and for +-inf: relu(inf) comes out NaN
+// instead of inf, relu(-inf) NaN instead of 0: still loud).  Deliberately NOT `x < 0 ? 0 : x`: in k_sa_fwd2_sb that form,
+// behind the SLP-packed v_pk_fma_f32 chain of layer 1, produced wrong and run-to-run different y2 tiles on gfx950 (round 4,
+// gpurun_out/r4e: 6.7e-2 instead of 1.2e-7 with `fmaxf`; v_cmp_ngt_f32 + v_cndmask_b32 on VCC; cause not isolated).
+__device__ __forceinline__ float relu_nan(float x) { return fmaf(x, 0.f, fmaxf(x, 0.f)); }
+
 // lanes strictly below this lane, as a 64-bit mask
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << lane_id()) - 1ull;
@@ -112,20 +119,27 @@ __device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, 
 // a*b = h1a*h1b + (h1a*h2b + h2a*h1b) + [h2a*h2b <= 2^-22 |a||b|, dropped].  fp16 x fp16 products are exact in fp32 and
 // v_mfma_f32_32x32x16_f16 accumulates in fp32: a GEMM built this way is 7e-8 from the exact product before accumulation
 // rounding (bf16x6: 6e-9; the fp32 accumulation both share: 2.4e-7), i.e. fp32-GEMM accuracy at HALF the MFMA work, 2/3
-// of the LDS plane traffic and ~2/3 of the split VALU of bf16x6.  What fp16 lacks is range: operands are pre-scaled by
-// exact powers of two (activations 2^4, weights 2^8: |a| < 4094, |w| < 255 before an fp16 overflow turns the result into
-// inf / NaN -- loudly; post-BatchNorm activations and network weights sit orders of magnitude inside) and the accumulator
-// is scaled back by 2^-12 in the epilogue.  Used for the FORWARD contractions; gradients (many orders of magnitude of
-// dynamic range) stay on bf16x6, which has fp32's exponent range.
+// of the LDS plane traffic and ~2/3 of the split VALU of bf16x6.
+// What fp16 lacks is range, so EVERY operand is pre-scaled by an exact power of two chosen from (a bound of) the operand's
+// own maximum -- the power of two that puts the maximum in [2^13, 2^14) (fp16 overflows at 2^16) -- and the accumulator is
+// scaled back by the exact inverse in the epilogue.  Round 4: no operand has a FIXED scale any more (rounds 1-3: activations
+// 2^4, weights 2^8, i.e. |a| < 4094, |w| < 255 or NaN, and 15-18 bits for uniformly tiny tensors):
+//   * weights: max|w| of the tensor (set-abstraction kernels: found by each workgroup while it splits the fragments) or of the
+//     32-column tile (row-streamed GEMMs: k_rs_planes, one scale per column tile stored behind the planes);
+//   * gradients: max|dy| maintained by the kernel that writes dy (64 hashed slots, rows.hip);
+//   * activations: a device-side BOUND of max|a| in the same 64-slot format -- train-mode BatchNorm outputs obey
+//     |gamma (y - mean) invstd + beta| <= |gamma| sqrt(n - 1) + |beta| (Samuelson's inequality; facl_bn_finalize writes it),
+//     pooled features carry their exact maximum (k_sa_pool), raw inputs / eval-mode layers a measured one (facl_absmax,
+//     facl_rows_act_amax).  A bound that is 2^t too large costs t of the 16 octaves below the maximum in which an element
+//     keeps its 22 bits; elements below that keep an absolute error <= 2^-38 of the bound.
+// Scales are clamped to [2^-40, 2^40] so that a scale, its inverse and the product of two inverses stay normal numbers: tensors
+// with maxima in [2^-27, 2^53] are inside the design range, beyond it precision degrades (tiny) or the result is inf (huge).
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 // smallest terms first: (lo,hi) (hi,lo) (hi,hi)
 #define FACL_H3_PA {1, 0, 0}
 #define FACL_H3_PB {0, 1, 0}
-#define FACL_H3_SA 16.0f
-#define FACL_H3_SW 256.0f
-#define FACL_H3_UNSCALE (1.0f / 4096.0f)
 // max|dy| of a gradient tensor is kept as float bits in FACL_AMAX_SLOTS slots FACL_AMAX_STRIDE dwords apart (rows.hip writes,
 // gemm_rs.hip reads); the buffer the C ABI calls `amax` is FACL_AMAX_SLOTS * FACL_AMAX_STRIDE uint32, zeroed by the caller
 #define FACL_AMAX_SLOTS 64
@@ -145,16 +159,45 @@ __device__ __forceinline__ f16x8h as_f16x8(unsigned a, unsigned b, unsigned c, u
     return __builtin_bit_cast(f16x8h, u);
 }
 
-// fp16x3 operand scale from the bits of max|x|: the power of two that puts the maximum in [2^13, 2^14) (fp16 overflows at
-// 2^16); sets `uns` = 1 / (scale * FACL_H3_SW).  max = 0 / denormal: the largest scale whose inverse stays normal.
-__device__ __forceinline__ float h3_dynamic_scale(const unsigned* amax, float& uns, float other_scale_log2) {
-    unsigned b = amax[(threadIdx.x & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE];    // one slot per lane (rows.hip: abs_max_slot)
+// biased exponent of the fp16x3 scale for a tensor whose maximum has the float bits `b` (>= 0): 2^(13 - floor(log2 max)),
+// clamped to [2^-40, 2^40] (max = 0 / denormal -> 2^40; inf / NaN -> 2^-40, and the NaN propagates through the products).
+// h3_se_wide: the clamp for GRADIENT-like operands (dy, G3), [2^-80, 2^80] -- losses and their gradients span far more
+// octaves than weights and normalised activations do.  One operand of a product may be wide: 381 - wide - narrow stays in
+// [7, 247], a normal number.
+__device__ __forceinline__ int h3_se(unsigned b) {
+    int se = 267 - (int)((b >> 23) & 0xff);
+    se = se > 167 ? 167 : se;
+    return se < 87 ? 87 : se;
+}
+__device__ __forceinline__ int h3_se_wide(unsigned b) {
+    int se = 267 - (int)((b >> 23) & 0xff);
+    se = se > 207 ? 207 : se;
+    return se < 47 ? 47 : se;
+}
+__device__ __forceinline__ float pow2_biased(int e) { return __uint_as_float((unsigned)e << 23); }
+// 1 / (2^(seA-127) 2^(seB-127)): biased exponent 381 - seA - seB (two narrow scales: [47, 207]; one wide: [7, 247])
+__device__ __forceinline__ float h3_unscale(int seA, int seB) { return pow2_biased(381 - seA - seB); }
+// wave-uniform maximum over the FACL_AMAX_SLOTS slots of an amax buffer (rows.hip: abs_max_slot writes them)
+__device__ __forceinline__ unsigned amax_bits(const unsigned* amax) {
+    unsigned b = amax[(threadIdx.x & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE];    // one slot per lane
 #pragma unroll
     for (int o = 32; o; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
-    const int e = (int)((__builtin_amdgcn_readfirstlane(b) >> 23) & 0xff);
-    int se = 267 - e;                                                   // biased exponent of 2^(13 - (e - 127))
-    se = se > 230 ? 230 : se;
-    const int ue = 254 - se - (int)other_scale_log2;                    // biased exponent of 2^-(se - 127) * 2^-other
-    uns = __uint_as_float((unsigned)ue << 23);
-    return __uint_as_float((unsigned)se << 23);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+}
+__device__ __forceinline__ int h3_se_of(const unsigned* amax) { return h3_se(amax_bits(amax)); }
+__device__ __forceinline__ int h3_se_wide_of(const unsigned* amax) { return h3_se_wide(amax_bits(amax)); }
+
+// max|w| over `n` floats, taken by the whole workgroup (all threads must call; two barriers) -> biased exponent of the scale.
+// `red`: >= 16 floats of LDS scratch that nobody else touches during the call.
+__device__ __forceinline__ int wg_h3_se(const float* __restrict__ w, int n, float* red) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) m = fmaxf(m, red[w2]);
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(h3_se(__float_as_uint(m)));
 }

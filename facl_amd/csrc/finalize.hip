@@ -35,26 +35,81 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
     }
 }
 
-__global__ void k_bn_finalize(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, float eps, float momentum,
-                              float* __restrict__ running_mean, float* __restrict__ running_var,
-                              float* __restrict__ bnc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = sums[2 * c] / count;
-    double var = sums[2 * c + 1] / count - mean * mean;
-    if (var < 0) var = 0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma[c], b = beta[c];
-    bnc[0 * C + c] = (float)mean;
-    bnc[1 * C + c] = (float)invstd;
-    bnc[2 * C + c] = (float)(g * invstd);
-    bnc[3 * C + c] = (float)(b - mean * g * invstd);
-    bnc[4 * C + c] = g < 0 ? -1.0f : 1.0f;
-    if (running_mean) {
-        const double unb = count > 1 ? var * count / (count - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+// One workgroup: channels strided over the threads.  `aamax` (or null): FACL_AMAX_WORDS uint32 that receive -- in every one of
+// the FACL_AMAX_SLOTS slots -- the bits of a BOUND of max|gamma (y - mean) invstd + beta| over the batch these statistics were
+// taken on: Samuelson's inequality, |y_i - mean| <= sigma sqrt(n - 1) for ANY n numbers, gives
+// |.| <= |gamma| sqrt(n - 1) sigma invstd + |beta| (sigma invstd = sqrt(var / (var + eps)) <= 1).  It is the fp16x3 scale of the
+// layer's activation (common.h) -- rigorous, no pass over the data, and within a few octaves of the true maximum.
+__global__ __launch_bounds__(1024) void k_bn_finalize(const double* __restrict__ sums, int C, double count,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      float momentum, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, float* __restrict__ bnc,
+                                                      unsigned* __restrict__ aamax) {
+    __shared__ float red[16];
+    float bound = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mean = sums[2 * c] / count;
+        double var = sums[2 * c + 1] / count - mean * mean;
+        if (var < 0) var = 0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma[c], b = beta[c];
+        bnc[0 * C + c] = (float)mean;
+        bnc[1 * C + c] = (float)invstd;
+        bnc[2 * C + c] = (float)(g * invstd);
+        bnc[3 * C + c] = (float)(b - mean * g * invstd);
+        bnc[4 * C + c] = g < 0 ? -1.0f : 1.0f;
+        if (running_mean) {
+            const double unb = count > 1 ? var * count / (count - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+        const double bd = (fabs(g) * sqrt((count > 1 ? count - 1 : 1) * var) * invstd + fabs(b)) * 1.001;   // 1.001: fp32 rounding of the constants
+        bound = fmaxf(bound, (float)bd);
+    }
+    if (!aamax) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bound;
+    __syncthreads();
+    if (threadIdx.x < FACL_AMAX_SLOTS) {
+        float m = red[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        aamax[threadIdx.x * FACL_AMAX_STRIDE] = __float_as_uint(m);
+    }
+}
+
+// max|x| of a contiguous fp32 array, RAISED into the FACL_AMAX_SLOTS slots of `amax` (zeroed by the caller, or holding the
+// maximum of another tensor that shares the scale): one atomic per wave, non-negative floats order like unsigned integers
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long long n, unsigned* __restrict__ amax) {
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+        atomicMax(amax + (wave & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE, __float_as_uint(m));
+    }
+}
+
+// max of relu(scale[c] y[r][c] + shift[c]) over a (R, C) row-major array: the measured activation maximum of an eval-mode
+// layer (running statistics give no bound on the data), raised into `amax` like k_absmax.  C % 4 == 0.
+__global__ __launch_bounds__(256) void k_rows_act_amax(const float* __restrict__ y, long long n4, int C4,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       unsigned* __restrict__ amax) {
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int c4 = (int)(i % C4);
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+        m = fmaxf(fmaxf(m, fmaxf(fmaf(sc.x, v.x, sh.x), fmaf(sc.y, v.y, sh.y))), fmaxf(fmaf(sc.z, v.z, sh.z), fmaf(sc.w, v.w, sh.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+        atomicMax(amax + (wave & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE, __float_as_uint(m));
     }
 }
 
@@ -95,14 +150,29 @@ __global__ void k_bn1_sums_from_moments(const double* __restrict__ mom, double c
 }
 
 // Fold BN1 into the first 1x1 conv: a1 = relu((scale*W1) x + (scale*b1 + shift)); rows of 8 floats.
+// `xamax` -> `a1amax` (both or neither): with X = max|x| over all coordinates (facl_absmax), |a1_c| <= X sum_i |w'_ci| + |b'_c|:
+// the bound of the layer-1 activation for eval-mode constants (train mode takes BatchNorm's own bound, facl_bn_finalize).
 __global__ void k_l1tab(const float* __restrict__ W1, const float* __restrict__ b1, int D,
-                        const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ tab) {
-    const int c = threadIdx.x;
-    if (c >= 64) return;
+                        const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ tab,
+                        const unsigned* __restrict__ xamax, unsigned* __restrict__ a1amax) {
+    const int c = threadIdx.x;                                          // 64 threads = one wave
     const float s = scale ? scale[c] : 1.0f, t = shift ? shift[c] : 0.0f;
-    for (int i = 0; i < 4; ++i) tab[c * 8 + i] = i < D ? s * W1[c * D + i] : 0.0f;
-    tab[c * 8 + 4] = s * b1[c] + t;
+    float l1 = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const float w = i < D ? s * W1[c * D + i] : 0.0f;
+        tab[c * 8 + i] = w;
+        l1 += fabsf(w);
+    }
+    const float b = s * b1[c] + t;
+    tab[c * 8 + 4] = b;
     tab[c * 8 + 5] = tab[c * 8 + 6] = tab[c * 8 + 7] = 0.0f;
+    if (a1amax) {
+        const float X = __uint_as_float(amax_bits(xamax));
+        float bd = fmaf(l1, X, fabsf(b)) * 1.001f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o, 64));
+        a1amax[c * FACL_AMAX_STRIDE] = __float_as_uint(bd);
+    }
 }
 
 }  // namespace
@@ -134,11 +204,31 @@ extern "C" int64_t facl_ws_bytes(void) { return (int64_t)FACL_WS_ROWS * 4608 * s
 
 extern "C" int facl_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* bnc,
-                                void* stream) {
+                                uint32_t* aamax, void* stream) {
     if (!sums || !gamma || !beta || !bnc) return FACL_E_NULL;
     if (C < 1 || count < 1) return FACL_E_SHAPE;
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, count, gamma,
-                       beta, eps, momentum, running_mean, running_var, bnc);
+    const int threads = C >= 1024 ? 1024 : (C + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(threads), 0, (hipStream_t)stream, sums, C, count, gamma,
+                       beta, eps, momentum, running_mean, running_var, bnc, aamax);
+    return facl_launch_status();
+}
+
+extern "C" int facl_absmax(const float* x, int64_t n, uint32_t* amax, void* stream) {
+    if (!x || !amax) return FACL_E_NULL;
+    if (n < 1) return FACL_E_SHAPE;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long long)n, amax);
+    return facl_launch_status();
+}
+
+extern "C" int facl_rows_act_amax(const float* y, int64_t R, int C, const float* scale, const float* shift, uint32_t* amax,
+                                  void* stream) {
+    if (!y || !scale || !shift || !amax) return FACL_E_NULL;
+    if (R < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
+    if ((((uintptr_t)y) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) return FACL_E_ALIGN;
+    const long long n4 = (long long)R * (C / 4);
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_rows_act_amax, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, n4, C / 4, scale, shift, amax);
     return facl_launch_status();
 }
 
@@ -161,10 +251,10 @@ extern "C" int facl_bn1_sums_from_moments(const double* mom, double count, int D
 }
 
 extern "C" int facl_sa_l1tab(const float* W1, const float* b1, int D, const float* scale, const float* shift,
-                             float* l1tab, void* stream) {
-    if (!W1 || !b1 || !l1tab) return FACL_E_NULL;
+                             float* l1tab, const uint32_t* xamax, uint32_t* a1amax, void* stream) {
+    if (!W1 || !b1 || !l1tab || ((xamax == nullptr) != (a1amax == nullptr))) return FACL_E_NULL;
     if (D != 3 && D != 4) return FACL_E_SHAPE;
-    hipLaunchKernelGGL(k_l1tab, dim3(1), dim3(64), 0, (hipStream_t)stream, W1, b1, D, scale, shift, l1tab);
+    hipLaunchKernelGGL(k_l1tab, dim3(1), dim3(64), 0, (hipStream_t)stream, W1, b1, D, scale, shift, l1tab, xamax, a1amax);
     return facl_launch_status();
 }
 

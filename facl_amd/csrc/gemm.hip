@@ -43,6 +43,7 @@ struct GemmArgs {
     const float* sgn; float* smax; int* sarg;
     int prec;                          // 0: fp32 result (bf16x6 or fp32 MFMA), 1: fp16 inputs, one MFMA product, fp32 accumulate
     const unsigned* amax;              // NP = 4 (fp16x3 weight gradient): bits of max|A| in hashed slots (common.h), A = dy
+    const unsigned* amax_b;            // NP = 4: bound of max|B| (the activation operand), same format
 };
 
 template <int LAY, int T>
@@ -95,8 +96,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
             if (PRO) {
                 const float4 s = *reinterpret_cast<const float4*>(ps + k0 + k);
                 const float4 t = *reinterpret_cast<const float4*>(pt + k0 + k);
-                v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
-                v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
+                v[0] = relu_nan(fmaf(s.x, v[0], t.x)); v[1] = relu_nan(fmaf(s.y, v[1], t.y));
+                v[2] = relu_nan(fmaf(s.z, v[2], t.z)); v[3] = relu_nan(fmaf(s.w, v[3], t.w));
             }
             *reinterpret_cast<float4*>(&T[il * LDK + k]) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -152,14 +153,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
                 if (i < g.MI && jin) { s += v; sq = fmaf(v, v, sq); }
                 if (TM == 2 && g.smax) {
                     const float sv = sg * v;
-                    if ((a == 0 && r == 0) || sv > best) { best = sv; bp = 32 * a + rowmap(r, 0); }
+                    if ((a == 0 && r == 0) || sv > best || sv != sv) { best = sv; bp = 32 * a + rowmap(r, 0); }   // a NaN wins and stays (MaxPool2d)
                 }
             }
         if (TM == 2 && g.smax) {                                           // the wave tile's 64 rows = one cloud
             bp += 4 * h;
             const float ob = __shfl_xor(best, 32, 64);
             const int op = __shfl_xor(bp, 32, 64);
-            if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }   // first max wins (MaxPool2d)
+            if ((ob > best || (ob == best && op < bp) || ob != ob) && best == best) { best = ob; bp = op; }   // first max wins; NaN stays (MaxPool2d)
             if (h == 0 && jin) {
                 const size_t o = (size_t)((i0 + WR * wr) >> 6) * g.NJ + j;
                 g.smax[o] = best;
@@ -238,7 +239,7 @@ __device__ __forceinline__ void gemm_epilogue_h(const GemmArgs& g, f32x16 (&acc)
                 if (i < g.MI && jin[b]) { s[b] += v; sq[b] = fmaf(v, v, sq[b]); }
                 if (TM == 2 && g.smax) {
                     const float sv = sg[b] * v;
-                    if ((a == 0 && r == 0) || sv > best[b]) { best[b] = sv; bp[b] = 32 * a + rowmap(r, 0); }
+                    if ((a == 0 && r == 0) || sv > best[b] || sv != sv) { best[b] = sv; bp[b] = 32 * a + rowmap(r, 0); }   // a NaN wins and stays
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // same-wave LDS hand-off (lanes swap roles)
@@ -266,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue_h(const GemmArgs& g, f32x16 (&acc)
             float bv = best[b];
             const float ob = __shfl_xor(bv, 32, 64);
             const int op = __shfl_xor(p, 32, 64);
-            if (ob > bv || (ob == bv && op < p)) { bv = ob; p = op; }      // first max wins (MaxPool2d)
+            if ((ob > bv || (ob == bv && op < p) || ob != ob) && bv == bv) { bv = ob; p = op; }      // first max wins; NaN stays (MaxPool2d)
             if (h == 0 && jin[b]) {
                 const size_t o = (size_t)((i0 + WR * wr) >> 6) * g.NJ + j;
                 g.smax[o] = bv;
@@ -557,7 +558,7 @@ __device__ __forceinline__ void split_tile_ic8(const float (&r)[8 * T], unsigned
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float x0 = r[8 * i + 2 * j], x1 = r[8 * i + 2 * j + 1];
-            if (PROI) { x0 = fmaxf(fmaf(ps, x0, pt), 0.f); x1 = fmaxf(fmaf(ps, x1, pt), 0.f); }
+            if (PROI) { x0 = relu_nan(fmaf(ps, x0, pt)); x1 = relu_nan(fmaf(ps, x1, pt)); }
             if (NP == 4) split_pair_h(x0 * sc, x1 * sc, pk[12 * i + j], pk[12 * i + 4 + j]);
             else if (NP >= 2) split_pair(x0, x1, pk[12 * i + j], pk[12 * i + 4 + j], pk[12 * i + 8 + j]);
             else pk[12 * i + j] = pk_f16(x0, x1);
@@ -587,8 +588,8 @@ __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigne
             const int k = 4 * (tid & 7);
             const float4 s = *reinterpret_cast<const float4*>(ps + k0 + k);
             const float4 t = *reinterpret_cast<const float4*>(pt + k0 + k);
-            v[0] = fmaxf(fmaf(s.x, v[0], t.x), 0.f); v[1] = fmaxf(fmaf(s.y, v[1], t.y), 0.f);
-            v[2] = fmaxf(fmaf(s.z, v[2], t.z), 0.f); v[3] = fmaxf(fmaf(s.w, v[3], t.w), 0.f);
+            v[0] = relu_nan(fmaf(s.x, v[0], t.x)); v[1] = relu_nan(fmaf(s.y, v[1], t.y));
+            v[2] = relu_nan(fmaf(s.z, v[2], t.z)); v[3] = relu_nan(fmaf(s.w, v[3], t.w));
         }
         if (NP >= 2) {
             split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
@@ -628,8 +629,11 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const TileId tile = xcd_tile();
-    float sca = 1.f, uns = 1.f;                                         // fp16x3: A = dy by its dynamic scale, B = activations by 2^4
-    if (NP == 4) sca = h3_dynamic_scale(g.amax, uns, 4.f);
+    float sca = 1.f, scb = 1.f, uns = 1.f;                              // fp16x3: A = dy and B = activations by their power-of-two scales
+    if (NP == 4) {
+        const int seA = h3_se_wide_of(g.amax), seB = h3_se_of(g.amax_b);
+        sca = pow2_biased(seA); scb = pow2_biased(seB); uns = h3_unscale(seA, seB);
+    }
     const int i0 = tile.y * BM, j0 = tile.x * BN;
     const int kbeg = tile.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.KK) ? kbeg + g.kchunk : g.KK;
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
         if (LA == KC) split_tile_kc4<PRO, TM, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
         else split_tile_ic8<TM, NP>(ra8, pka, 1.f, 0.f, sca);
         if (LB == KC) split_tile_kc4<false, TN, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
-        else split_tile_ic8<TN, NP, PROB>(rb8, pkb, psb, ptb, FACL_H3_SA);
+        else split_tile_ic8<TN, NP, PROB>(rb8, pkb, psb, ptb, scb);
     };
     auto write = [&]() {
         if (LA == KC) write_tile_kc4<TM, NP>(sA, pka, tid);
@@ -1077,11 +1081,13 @@ static int gemm_wgrad_pro_p(const float* dy, const float* y, int64_t M, int N, i
 }
 
 // fp16x3 weight gradient on the 128x128-tile kernel: dW (N,K) = dy^T f(y), f = relu(pscale*y + pshift) per column when pscale
-// is given, else identity; dy by the dynamic power-of-two scale read from `amax` (facl_rows_bwd_apply_amax), f(y) by 2^4
-// (|f(y)| < 4094).  FACL_E_CONFIG when the shape is not served (callers use the bf16x6 entries).
+// is given, else identity; dy by the power-of-two scale read from `amax` (facl_rows_bwd_apply_amax), f(y) by the one read
+// from `amax_b` (the bound the forward GEMM that consumed f(y) was given).  FACL_E_CONFIG when the shape is not served
+// (callers use the bf16x6 entries).
 extern "C" int facl_gemm_wgrad_h3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
-                                  const float* pshift, const uint32_t* amax, float* dW, float* slices, int nz, void* stream) {
-    if (!dy || !y || !amax || !dW || !slices || (pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
+                                  const float* pshift, const uint32_t* amax, const uint32_t* amax_b, float* dW, float* slices,
+                                  int nz, void* stream) {
+    if (!dy || !y || !amax || !amax_b || !dW || !slices || (pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
     if (M < 1 || M > 0x7fffffff || N < 4 || (N & 3) || K < 4 || (K & 3) || nz < 1 || nz > 1024) return FACL_E_SHAPE;
     static const int use_f32 = getenv("FACL_GEMM_F32") ? atoi(getenv("FACL_GEMM_F32")) : 0;
     if (use_f32) return FACL_E_CONFIG;
@@ -1089,7 +1095,7 @@ extern "C" int facl_gemm_wgrad_h3(const float* dy, const float* y, int64_t M, in
     int kchunk = (int)((M + nz - 1) / nz);
     kchunk = (kchunk + BK - 1) / BK * BK;
     nz = (int)((M + kchunk - 1) / kchunk);
-    GemmArgs g{dy, N, y, ldy, slices, K, N, K, (int)M, nullptr, pscale, pshift, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr, 0, amax};
+    GemmArgs g{dy, N, y, ldy, slices, K, N, K, (int)M, nullptr, pscale, pshift, nullptr, nullptr, 0, nullptr, kchunk, nullptr, nullptr, nullptr, 0, amax, amax_b};
     const long long big = (long long)((K + 127) / 128) * ((N + 127) / 128) * nz;
     if (big < 256 || sbk_fits(g, nz)) return FACL_E_CONFIG;
     dim3 grid((K + 127) / 128, (N + 127) / 128, nz);

@@ -53,8 +53,9 @@ struct RsArgs {
     // (sum_r d, sum_r d * yhat), d = C[r] where scale*y + shift > 0 else 0, yhat = (y - mean) * invstd
     const float* by; const float* bbnc;
     int h3;                                       // 1: fp16x3 planes / arithmetic, 0: bf16x6
-    const unsigned* amax;                         // h3 only: bits of max|A| (device scalar) -> the power-of-two scale of A is
-                                                  // chosen per launch (gradients); null: the fixed activation scale 2^4
+    const unsigned* amax;                         // h3 only: bits of (a bound of) max|A| in FACL_AMAX_SLOTS slots -> the
+                                                  // power-of-two scale of A (activations: their bound, gradients: max|dy|)
+    const int* wse;                               // h3 only: biased exponent of the weight scale per 32-column tile (k_rs_planes)
 };
 
 
@@ -64,18 +65,19 @@ struct RsArgs {
 // sc = 1 (y = a W^T); dgrad: so = 1, sc = ldw (da = dy W).  Entry ((ks*NT + o/32)*3 + plane)*64 + 32h + o%32 holds the 8
 // k-slots c = 16ks + 8h + j of column o.  `xc` (forward only): one more k-step whose slots 0..2 (h = 0) are
 // Wc[o][0..2] -- the centroid-xyz columns of torch.cat((yt, xt), 1), cn3d_model_conbag.py:219.
-// `half`: fp16x3 planes (common.h): TWO planes per fragment (h1, h2 of w * 2^8) instead of three bf16 planes; same indexing
-// with 2 in place of 3.
-__global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
-                                                   const float* __restrict__ xc, int ldxc, uint4* __restrict__ out, int half) {
-    const int NT = NO >> 5, nks = NC >> 4;
-    const long long total = (long long)(nks + (xc ? 1 : 0)) * NT * 64;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ln = (int)(i & 63);
-        const long long t = i >> 6;
-        const int ot = (int)(t % NT), ks = (int)(t / NT);
+// `half`: fp16x3 planes (common.h): TWO planes per fragment (h1, h2 of w * scale) instead of three bf16 planes; same indexing
+// with 2 in place of 3.  The scale is a power of two PER 32-COLUMN TILE (output columns are independent, so the epilogue
+// can undo it per tile): 2^(13 - floor(log2 max|w|)) over the tile's 32 columns x the whole contraction (centre columns
+// included), stored as its biased exponent in `hdr[tile]` behind the planes.  One workgroup per (matrix, column tile): a
+// first pass over the tile takes the maximum, a second one splits (the tile is 4-128 KiB: L2 hits).
+__device__ __forceinline__ void rs_planes_tile(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
+                                               const float* __restrict__ xc, int ldxc, uint4* __restrict__ out, int half,
+                                               int* __restrict__ hdr, int ot) {
+    __shared__ float red[16];
+    const int NT = NO >> 5, nks = NC >> 4, nitems = (nks + (xc ? 1 : 0)) * 64;
+    auto load8 = [&](int item, float (&v)[8]) {
+        const int ln = item & 63, ks = item >> 6;
         const int o = 32 * ot + (ln & 31), hh = ln >> 5;
-        float v[8];
         if (ks < nks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = W[(long long)o * so + (long long)(16 * ks + 8 * hh + j) * sc];
@@ -83,10 +85,33 @@ __global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (hh == 0 && j < 3) ? xc[(long long)o * ldxc + j] : 0.f;
         }
+    };
+    float sw = 1.f;
+    if (half) {
+        float m = 0.f;
+        for (int item = threadIdx.x; item < nitems; item += 256) {
+            float v[8];
+            load8(item, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const int se = h3_se(__float_as_uint(m));
+        if (threadIdx.x == 0) hdr[ot] = se;
+        sw = pow2_biased(se);
+    }
+    for (int item = threadIdx.x; item < nitems; item += 256) {
+        const int ln = item & 63, ks = item >> 6;
+        float v[8];
+        load8(item, v);
         unsigned hi[4], mi[4], lo[4];
         if (half) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j] * FACL_H3_SW, v[2 * j + 1] * FACL_H3_SW, hi[j], lo[j]);
+            for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j] * sw, v[2 * j + 1] * sw, hi[j], lo[j]);
             uint4* d = out + ((long long)(ks * NT + ot) * 2) * 64 + ln;
             d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             d[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
@@ -101,50 +126,27 @@ __global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, 
     }
 }
 
+__global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
+                                                   const float* __restrict__ xc, int ldxc, uint4* __restrict__ out, int half,
+                                                   int* __restrict__ hdr) {
+    rs_planes_tile(W, so, sc, NO, NC, xc, ldxc, out, half, hdr, blockIdx.x);
+}
+
 // several weight matrices in one launch (the forward and dgrad planes of the three layers of net3DV_3: one ~8 us launch
-// per step instead of six)
+// per step instead of six); block b serves column tile b - first[j] of matrix j
 constexpr int RS_MAXJOBS = 8;
 struct RsPlaneJobs {
     int n;
     const float* W[RS_MAXJOBS]; long long so[RS_MAXJOBS]; long long sc[RS_MAXJOBS]; int NO[RS_MAXJOBS]; int NC[RS_MAXJOBS];
-    const float* xc[RS_MAXJOBS]; int ldxc[RS_MAXJOBS]; uint4* out[RS_MAXJOBS]; long long first[RS_MAXJOBS + 1];
+    const float* xc[RS_MAXJOBS]; int ldxc[RS_MAXJOBS]; uint4* out[RS_MAXJOBS]; int* hdr[RS_MAXJOBS]; int first[RS_MAXJOBS + 1];
     int half[RS_MAXJOBS];
 };
 __global__ __launch_bounds__(256) void k_rs_planes_multi(RsPlaneJobs jb) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < jb.first[jb.n]; i += (long long)gridDim.x * 256) {
-        int j = 0;
+    int j = 0;
 #pragma unroll
-        for (int t = 1; t < RS_MAXJOBS; ++t) j += (t < jb.n && i >= jb.first[t]) ? 1 : 0;
-        const long long li = i - jb.first[j];
-        const int NT = jb.NO[j] >> 5, nks = jb.NC[j] >> 4;
-        const int ln = (int)(li & 63);
-        const long long t = li >> 6;
-        const int ot = (int)(t % NT), ks = (int)(t / NT);
-        const int o = 32 * ot + (ln & 31), hh = ln >> 5;
-        float v[8];
-        if (ks < nks) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = jb.W[j][(long long)o * jb.so[j] + (long long)(16 * ks + 8 * hh + e) * jb.sc[j]];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (hh == 0 && e < 3) ? jb.xc[j][(long long)o * jb.ldxc[j] + e] : 0.f;
-        }
-        unsigned hi[4], mi[4], lo[4];
-        if (jb.half[j]) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split_pair_h(v[2 * e] * FACL_H3_SW, v[2 * e + 1] * FACL_H3_SW, hi[e], lo[e]);
-            uint4* d = jb.out[j] + ((long long)(ks * NT + ot) * 2) * 64 + ln;
-            d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            d[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            continue;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
-        uint4* d = jb.out[j] + ((long long)(ks * NT + ot) * 3) * 64 + ln;
-        d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
-        d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    }
+    for (int t = 1; t < RS_MAXJOBS; ++t) j += (t < jb.n && (int)blockIdx.x >= jb.first[t]) ? 1 : 0;
+    rs_planes_tile(jb.W[j], jb.so[j], jb.sc[j], jb.NO[j], jb.NC[j], jb.xc[j], jb.ldxc[j], jb.out[j], jb.half[j], jb.hdr[j],
+                   (int)blockIdx.x - jb.first[j]);
 }
 
 struct RsTile { int x, y; };
@@ -191,8 +193,9 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     const int row0 = (tile.y * RS_WAVES + wave) * 32;
     const int nks = g.K >> 4, nst = g.K >> 5;
     const int nks_all = nks + (g.centers ? 1 : 0);
-    float sA = FACL_H3_SA, uns = FACL_H3_UNSCALE;                       // fp16x3: scale of the A operand, 1 / (sA * 2^8)
-    if (H3 && g.amax) sA = h3_dynamic_scale(g.amax, uns, 8.f);
+    int seA = 127;                                                      // fp16x3: biased exponent of the A operand's scale
+    if (H3) seA = h3_se_wide_of(g.amax);                                // the wide clamp: A is a gradient in the dgrad form
+    const float sA = pow2_biased(seA);
 
     if (PRO) {
         for (int i = tid; i < g.K; i += 64 * RS_WAVES) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
@@ -246,8 +249,9 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         if (PRO) {
             const float4 s4 = *reinterpret_cast<const float4*>(tab + 16 * j + 8 * h + 4 * half);
             const float4 t4 = *reinterpret_cast<const float4*>(tab + RS_KPRO + 16 * j + 8 * h + 4 * half);
-            v[0] = fmaxf(fmaf(s4.x, v[0], t4.x), 0.f); v[1] = fmaxf(fmaf(s4.y, v[1], t4.y), 0.f);
-            v[2] = fmaxf(fmaf(s4.z, v[2], t4.z), 0.f); v[3] = fmaxf(fmaf(s4.w, v[3], t4.w), 0.f);
+            // NaN-propagating ReLU (torch.relu keeps NaN; fmaxf(NaN, 0) = 0 would turn a poisoned input into a clean zero)
+            v[0] = relu_nan(fmaf(s4.x, v[0], t4.x)); v[1] = relu_nan(fmaf(s4.y, v[1], t4.y));
+            v[2] = relu_nan(fmaf(s4.z, v[2], t4.z)); v[3] = relu_nan(fmaf(s4.w, v[3], t4.w));
         }
         if (H3) {
             split_pair_h(v[0] * sA, v[1] * sA, pk[2 * half], pk[4 + 2 * half]);
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
         const int n = 256 * cb + 32 * ct + q;
         const float bias = g.bias ? g.bias[n] : 0.f;
         const float sg = SEG ? sgn_of(g.sgn[n]) : 1.f;
+        const float uns = H3 ? h3_unscale(seA, g.wse[RS_CT * cb + ct]) : 1.f;       // this column tile's 1 / (sA sW): exact
         float s = 0.f, sq = 0.f, best = 0.f;
         int bp = 0;
         float bmean = 0.f, binv = 0.f, bsc = 0.f, bsh = 0.f;
@@ -449,6 +454,10 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
             const float ob = __shfl_xor(best, 32, 64);
             const int op = __shfl_xor(bp, 32, 64);
             if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }          // first max wins (MaxPool2d)
+            // MaxPool2d propagates NaN; the compares above skip it.  The column sum over the wave's 32 rows is NaN / inf exactly
+            // when one of them is: s - s is then NaN (else +0) and poisons the maximum at the cost of three instructions per tile
+            const float stp = s + __shfl_xor(s, 32, 64);
+            best += stp - stp;
             if (wave & 1) {
                 if (h == 0) { wbest[2 * (32 * ct + q)] = best; wbest[2 * (32 * ct + q) + 1] = __int_as_float(bp); }
             } else {
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
                 int bp = __float_as_int(acc[ct][1]);
                 const float ob = pb[2 * (32 * ct + q)];
                 if (ob > best) { best = ob; bp = 32 + __float_as_int(pb[2 * (32 * ct + q) + 1]); }
+                best += ob - ob;                                                       // the partner's poison (NaN / inf), else +0
                 const size_t o = (size_t)cloud * g.N + 256 * cb + 32 * ct + q;
                 g.smax[o] = best;
                 g.sarg[o] = bp;
@@ -504,7 +514,8 @@ struct WgArgs {
     const float* dy; const float* y; int M, N, K;     // dy (M,N), y (M,K) row-major
     const float* pscale; const float* pshift;         // (K) or null
     float* slices; int rows_per_slice;                // slices[z][N][K]; rows_per_slice % 32 == 0
-    const unsigned* amax;                             // fp16x3 form: bits of max|dy| (device scalar)
+    const unsigned* amax;                             // fp16x3 form: bits of max|dy| (FACL_AMAX_SLOTS slots)
+    const unsigned* amax_b;                           // fp16x3 form: bound of max|f(y)| (same format)
 };
 
 // H3: fp16x3 arithmetic (common.h): dy scaled by the power of two that puts max|dy| in [2^13, 2^14), f(y) by 2^4, two fp16
@@ -527,8 +538,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
     const int p0 = bz * g.rows_per_slice;
     const int p1 = p0 + g.rows_per_slice < g.M ? p0 + g.rows_per_slice : g.M;
     const int nst = (p1 - p0 + 31) >> 5;                                           // stages of 32 rows (the last may be ragged)
-    float sD = 1.f, uns = 1.f;
-    if (H3) sD = h3_dynamic_scale(g.amax, uns, 4.f);
+    float sD = 1.f, sB = 1.f, uns = 1.f;
+    if (H3) {
+        const int seD = h3_se_wide_of(g.amax), seB = h3_se_of(g.amax_b);
+        sD = pow2_biased(seD); sB = pow2_biased(seB); uns = h3_unscale(seD, seB);
+    }
 
     // producer role: this thread's fragment of a stage = (k-step ks_b, k tile kt_b, lane lb): channel kb, rows 16 ks_b + 8 hb + e
     const int ks_b = tid >> 8, kt_b = (tid >> 6) & 3, lb = tid & 63;
@@ -547,12 +561,12 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
     auto store_b = [&](int s, const float (&r)[8]) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = PRO ? fmaxf(fmaf(ps, r[e], pt), 0.f) : r[e];
+        for (int e = 0; e < 8; ++e) v[e] = PRO ? relu_nan(fmaf(ps, r[e], pt)) : r[e];
         unsigned hi[4], mi[4], lo[4];
         uint4* d = &bring[s & 1][((ks_b * 4 + kt_b) * NPL) * 64 + lb];
         if (H3) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_pair_h(v[2 * e] * FACL_H3_SA, v[2 * e + 1] * FACL_H3_SA, hi[e], mi[e]);
+            for (int e = 0; e < 4; ++e) split_pair_h(v[2 * e] * sB, v[2 * e + 1] * sB, hi[e], mi[e]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hi[e], mi[e], lo[e]);
@@ -696,7 +710,12 @@ __global__ void k_wg_sum_slices(const float* __restrict__ part, int nz, long lon
 }
 
 int rs_launch(const RsArgs& g, hipStream_t st) {
-    static bool attr_done = false;
+    // the 68 KiB dynamic-LDS attribute is per device: one flag per device ordinal (a process may drive several devices, and a
+    // forward on the main thread can race a backward on the autograd thread: the worst case sets the attribute twice)
+    static bool attr_done_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    bool& attr_done = attr_done_dev[dev];
     if (!attr_done) {
         const void* fns[10] = {(const void*)k_gemm_rs<false, false, true, true>,(const void*)k_gemm_rs<false, false, false>, (const void*)k_gemm_rs<true, false, false>,
                               (const void*)k_gemm_rs<false, true, false>, (const void*)k_gemm_rs<true, true, false>,
@@ -726,9 +745,14 @@ int rs_launch(const RsArgs& g, hipStream_t st) {
 
 }  // namespace
 
+// bytes of the plane buffer of a matrix with N OUTPUT columns and contraction K: the planes (sized for the three-plane form)
+// followed by the per-column-tile scale exponents (N/32 int32, padded to 256 B)
+static int64_t rs_planes_only_bytes(int N, int K, int with_centers) {
+    return (int64_t)(K / 16 + (with_centers ? 1 : 0)) * (N / 32) * 3 * 64 * 16;
+}
 extern "C" int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers) {
     if (N < 32 || K < 16) return 0;
-    return (int64_t)(K / 16 + (with_centers ? 1 : 0)) * (N / 32) * 3 * 64 * 16;          // sized for the three-plane form
+    return rs_planes_only_bytes(N, K, with_centers) + (((int64_t)(N / 32) * 4 + 255) / 256) * 256;
 }
 
 // planes for y = a W^T (transposed = 0: W (N,K) row-major, leading dimension ldw; output columns N, contraction K;
@@ -741,10 +765,9 @@ extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int tr
     const int NO = transposed ? K : N, NC = transposed ? N : K;
     if ((NO & 31) || (NC & 15) || (transposed && Wc)) return FACL_E_SHAPE;
     const long long so = transposed ? 1 : ldw, sc = transposed ? ldw : 1;
-    const long long total = (long long)(NC / 16 + (Wc ? 1 : 0)) * (NO / 32) * 64;
-    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_rs_planes, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes,
-                       half ? 1 : 0);
+    int* hdr = (int*)((char*)planes + rs_planes_only_bytes(NO, NC, Wc ? 1 : 0));
+    hipLaunchKernelGGL(k_rs_planes, dim3(NO / 32), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes,
+                       half ? 1 : 0, hdr);
     return facl_launch_status();
 }
 
@@ -758,19 +781,18 @@ extern "C" int facl_gemm_rs_planes_multi(int n, const float* const* W, const int
     jb.n = n;
     jb.first[0] = 0;
     for (int j = 0; j < RS_MAXJOBS; ++j) {
-        if (j >= n) { jb.W[j] = nullptr; jb.xc[j] = nullptr; jb.out[j] = nullptr; jb.so[j] = jb.sc[j] = 0; jb.NO[j] = jb.NC[j] = 32; jb.ldxc[j] = 0; jb.half[j] = 0; jb.first[j + 1] = jb.first[j]; continue; }
+        if (j >= n) { jb.W[j] = nullptr; jb.xc[j] = nullptr; jb.out[j] = nullptr; jb.hdr[j] = nullptr; jb.so[j] = jb.sc[j] = 0; jb.NO[j] = jb.NC[j] = 32; jb.ldxc[j] = 0; jb.half[j] = 0; jb.first[j + 1] = jb.first[j]; continue; }
         if (!W[j] || !planes[j]) return FACL_E_NULL;
         if (N[j] < 1 || K[j] < 1 || ldw[j] < K[j]) return FACL_E_SHAPE;
         const int NO = transposed[j] ? K[j] : N[j], NC = transposed[j] ? N[j] : K[j];
         if ((NO & 31) || (NC & 15) || (transposed[j] && Wc[j])) return FACL_E_SHAPE;
         jb.W[j] = W[j]; jb.so[j] = transposed[j] ? 1 : ldw[j]; jb.sc[j] = transposed[j] ? ldw[j] : 1;
         jb.NO[j] = NO; jb.NC[j] = NC; jb.xc[j] = Wc[j]; jb.ldxc[j] = ldwc[j]; jb.out[j] = (uint4*)planes[j];
+        jb.hdr[j] = (int*)((char*)planes[j] + rs_planes_only_bytes(NO, NC, Wc[j] ? 1 : 0));
         jb.half[j] = half[j] ? 1 : 0;
-        jb.first[j + 1] = jb.first[j] + (long long)(NC / 16 + (Wc[j] ? 1 : 0)) * (NO / 32) * 64;
+        jb.first[j + 1] = jb.first[j] + NO / 32;
     }
-    const long long total = jb.first[n];
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_rs_planes_multi, dim3(grid), dim3(256), 0, (hipStream_t)stream, jb);
+    hipLaunchKernelGGL(k_rs_planes_multi, dim3(jb.first[n]), dim3(256), 0, (hipStream_t)stream, jb);
     return facl_launch_status();
 }
 
@@ -783,10 +805,13 @@ extern "C" int facl_gemm_rs_supported(int64_t M, int K, int N) {
 // f = relu(pscale*a + pshift) per input channel when pscale is given (the previous layer's BatchNorm + ReLU).
 // sums (N,2): per-column (sum, sumsq) of y (or null).  sgn / ymax / arg (all or none): fused my_max_pool over blocks of 64
 // rows as in facl_gemm_fwd_segmax (M % 64 == 0).
-extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, int N, const float* bias,
-                                const float* pscale, const float* pshift, const float* centers, float* y, double* sums,
-                                const float* sgn, float* ymax, int32_t* arg, void* ws, void* stream) {
-    if (!a || !planes || !y || (sums && !ws)) return FACL_E_NULL;
+// half = 1 (fp16x3): `amax_a` = FACL_AMAX_WORDS uint32 holding the bits of (a bound of) max|f(a)| and, with centres, of
+// max|centre coordinate| (the centre k-step shares A's scale); facl_bn_finalize / facl_sa_pool / facl_absmax /
+// facl_rows_act_amax produce it.
+extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, const uint32_t* amax_a, int N,
+                                const float* bias, const float* pscale, const float* pshift, const float* centers, float* y,
+                                double* sums, const float* sgn, float* ymax, int32_t* arg, void* ws, void* stream) {
+    if (!a || !planes || !y || (sums && !ws) || (half && !amax_a)) return FACL_E_NULL;
     if (!facl_gemm_rs_supported(M, K, N)) return FACL_E_SHAPE;
     if ((pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
     if (pscale && K > RS_KPRO) return FACL_E_SHAPE;
@@ -796,8 +821,9 @@ extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* pl
     const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     if (sums && (size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(N, K, centers ? 1 : 0));
     RsArgs g{a, K, (int)M, K, (const uint4*)planes, N / 32, N, bias, pscale, pshift, centers, y, N,
-             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr, half ? 1 : 0, nullptr};
+             sums ? (double*)ws : nullptr, sgn, ymax, arg, nullptr, nullptr, half ? 1 : 0, amax_a, wse};
     int rc = rs_launch(g, st);
     if (rc || !sums) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
@@ -811,8 +837,9 @@ extern "C" int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void*
     if (!dy || !planes || !da || (half && !amax)) return FACL_E_NULL;
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
+    const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(K, N, 0));
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, half ? 1 : 0, amax};
+             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, half ? 1 : 0, amax, wse};
     return rs_launch(g, (hipStream_t)stream);
 }
 
@@ -829,8 +856,9 @@ extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, con
     const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     if ((size_t)prow * K * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(K, N, 0));
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,
-             (double*)ws, nullptr, nullptr, nullptr, y, bnc, half ? 1 : 0, amax};
+             (double*)ws, nullptr, nullptr, nullptr, y, bnc, half ? 1 : 0, amax, wse};
     int rc = rs_launch(g, st);
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, prow, 2 * K, sums, st);
@@ -850,10 +878,12 @@ extern "C" int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K) {
     rps = (rps + 31) / 32 * 32;
     return (int)((M + rps - 1) / rps);
 }
-// amax (or null): fp16x3 arithmetic with dy's scale taken from the bits of max|dy| it points to (device scalar).
+// amax (or null): fp16x3 arithmetic with dy's scale taken from the bits of max|dy| it points to; `amax_b` (required with
+// amax): the bound of max|f(y)| in the same format (the one the forward GEMM that consumed f(y) was given).
 extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale,
-                                  const float* pshift, const uint32_t* amax, float* dW, float* slices, void* stream) {
-    if (!dy || !y || !dW || !slices) return FACL_E_NULL;
+                                  const float* pshift, const uint32_t* amax, const uint32_t* amax_b, float* dW, float* slices,
+                                  void* stream) {
+    if (!dy || !y || !dW || !slices || (amax && !amax_b)) return FACL_E_NULL;
     if ((pscale == nullptr) != (pshift == nullptr)) return FACL_E_NULL;
     if (M > 0x7fffffff) return FACL_E_SHAPE;
     const int nz = facl_gemm_rs_wgrad_slices(M, N, K);
@@ -865,7 +895,7 @@ extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, in
     int rps = (int)((M + nz0 - 1) / nz0);
     rps = (rps + 31) / 32 * 32;
     hipStream_t st = (hipStream_t)stream;
-    WgArgs g{dy, y, (int)M, N, K, pscale, pshift, slices, rps, amax};
+    WgArgs g{dy, y, (int)M, N, K, pscale, pshift, slices, rps, amax, amax_b};
     dim3 grid(K / 128, N / 512, nz);
     const dim3 blk(64 * WG_WAVES);
     if (pscale && amax) hipLaunchKernelGGL((k_wgrad_rs<true, true>), grid, blk, 0, st, g);

@@ -37,8 +37,8 @@ __global__ void k_rows_bn_relu(const float* __restrict__ y, long long n4, int C4
         const float4 v = reinterpret_cast<const float4*>(y)[i];
         const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
         float4 o;
-        o.x = fmaxf(fmaf(sc.x, v.x, sh.x), 0.f); o.y = fmaxf(fmaf(sc.y, v.y, sh.y), 0.f);
-        o.z = fmaxf(fmaf(sc.z, v.z, sh.z), 0.f); o.w = fmaxf(fmaf(sc.w, v.w, sh.w), 0.f);
+        o.x = relu_nan(fmaf(sc.x, v.x, sh.x)); o.y = relu_nan(fmaf(sc.y, v.y, sh.y));
+        o.z = relu_nan(fmaf(sc.z, v.z, sh.z)); o.w = relu_nan(fmaf(sc.w, v.w, sh.w));
         reinterpret_cast<float4*>(out)[i] = o;
     }
 }
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(256) void k_rows_segmax(const float* __restrict__ y
     int bi = 0;
     for (int s = 1; s < S; ++s) {
         const float v = sgn * base[(size_t)s * C];
-        if (v > best) { best = v; bi = s; }
+        if (v > best || v != v) { best = v; bi = s; }                          // a NaN wins and stays (MaxPool2d propagates it)
     }
-    out[(size_t)m * C + c] = fmaxf(fmaf(fabsf(scale), best, shift), 0.f);
+    out[(size_t)m * C + c] = relu_nan(fmaf(fabsf(scale), best, shift));
     arg[(size_t)m * C + c] = bi;
 }
 
@@ -300,10 +300,10 @@ __global__ __launch_bounds__(256) void k_viewmax_fwd(const float* __restrict__ x
     int4 bi = make_int4(0, 0, 0, 0);
     for (int g = 1; g < G; ++g) {
         const float4 v = reinterpret_cast<const float4*>(x)[((size_t)g * B + b) * C4 + c4];
-        if (v.x > best.x) { best.x = v.x; bi.x = g; }
-        if (v.y > best.y) { best.y = v.y; bi.y = g; }
-        if (v.z > best.z) { best.z = v.z; bi.z = g; }
-        if (v.w > best.w) { best.w = v.w; bi.w = g; }
+        if (v.x > best.x || v.x != v.x) { best.x = v.x; bi.x = g; }
+        if (v.y > best.y || v.y != v.y) { best.y = v.y; bi.y = g; }
+        if (v.z > best.z || v.z != v.z) { best.z = v.z; bi.z = g; }
+        if (v.w > best.w || v.w != v.w) { best.w = v.w; bi.w = g; }
     }
     reinterpret_cast<float4*>(out)[i] = best;
     reinterpret_cast<int4*>(arg)[i] = bi;

@@ -96,9 +96,10 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
                                                  const float* __restrict__ bnc2, const float* __restrict__ G3,
                                                  const float* __restrict__ h3, const float* __restrict__ W3,
                                                  const float* __restrict__ coef, const unsigned char* __restrict__ arg,
-                                                 float* __restrict__ dz2f, double* __restrict__ part) {
+                                                 float* __restrict__ dz2f, double* __restrict__ part,
+                                                 const unsigned* __restrict__ a2amax) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float g3scale, g3uns;
+    float g3scale, g3uns, hs;                             // hs = (G3 scale)(a2 scale): what the accumulators ride at
     float* w3n = reinterpret_cast<float*>(lds4 + 1024);   // W3 natural (256,64)
     float4* tab = lds4 + 1024 + 4096;                     // mean2, invstd2, scale2, shift2, h3: 5 x 16 float4
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,11 +127,17 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
         for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
         __syncthreads();
         // scale 2^(13 - floor(log2 m)) (m = 0, denormal or huge: clamped so that scale and its inverse stay normal)
-        int se = 267 - (int)((__float_as_uint(m) >> 23) & 0xff);
-        se = se > 230 ? 230 : se;
-        se = __builtin_amdgcn_readfirstlane(se);                       // wave-uniform: keep the two factors in scalar registers
-        g3scale = __uint_as_float((unsigned)se << 23);
-        g3uns = __uint_as_float((unsigned)(254 - se - 4) << 23);      // 1 / (scale * 2^4): the activations ride at 2^4
+        const int se = __builtin_amdgcn_readfirstlane(h3_se_wide(__float_as_uint(m)));   // wave-uniform: the factors stay in scalar registers
+        const int seA2 = h3_se_of(a2amax);                             // fp16x3 scale of a2 = relu(bn2(y2)): the bound the forward used
+        g3scale = pow2_biased(se);
+        g3uns = h3_unscale(se, seA2);                                  // 1 / (G3 scale * a2 scale)
+        hs = g3scale * pow2_biased(seA2);
+        if (threadIdx.x >= 32 && threadIdx.x < 64) {                   // (scale2, shift2) ride at a2's scale: relu(s sc y + s sh) = s relu(sc y + sh)
+            const float sA2 = pow2_biased(seA2);                       // exactly for a power of two s; the sign test of the ReLU mask is unchanged
+            float4 t = reinterpret_cast<const float4*>(bnc2)[threadIdx.x];
+            t.x *= sA2; t.y *= sA2; t.z *= sA2; t.w *= sA2;
+            tab[threadIdx.x] = t;
+        }
     }
     for (int i = threadIdx.x; i < 512; i += 512) {
         const int ln = i & 63, kb = (i >> 6) & 3, ro = i >> 8;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
     }
     for (int i = threadIdx.x; i < 4096; i += 512)
         reinterpret_cast<float4*>(w3n)[i] = reinterpret_cast<const float4*>(W3)[i];
-    if (threadIdx.x < 64) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2)[threadIdx.x];   // 4 x 64 floats
+    if (threadIdx.x < 32) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2)[threadIdx.x];   // mean2, invstd2 (scale2, shift2: above)
     if (threadIdx.x < 16) tab[64 + threadIdx.x] = reinterpret_cast<const float4*>(h3)[threadIdx.x];
     __syncthreads();
     const float4* mean2 = tab; const float4* inv2 = tab + 16; const float4* sc2 = tab + 32; const float4* sh2 = tab + 48;
@@ -243,7 +250,6 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4 hh = h3s[8 * ro + 2 * r4 + h];
-                const float hs = g3scale * FACL_H3_SA;                     // the accumulator runs at (G3 scale)(2^4)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     acc[ct][4 * r4] = hh.x * hs; acc[ct][4 * r4 + 1] = hh.y * hs; acc[ct][4 * r4 + 2] = hh.z * hs; acc[ct][4 * r4 + 3] = hh.w * hs;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(512) void k_sa_bwd1(const float* __restrict__ y2f, 
                 for (int ct = 0; ct < 2; ++ct) {
                     float a2[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) a2[t] = fmaxf(fmaf(scv[t], yv[ct][rt][8 * mm + t], shv[t]), 0.f) * FACL_H3_SA;
+                    for (int t = 0; t < 8; ++t) a2[t] = fmaxf(fmaf(scv[t], yv[ct][rt][8 * mm + t], shv[t]), 0.f);   // a2 * sA2 (tables)
                     unsigned hi[4], lo[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) split_pair_h(a2[2 * t], a2[2 * t + 1], hi[t], lo[t]);
@@ -340,14 +346,21 @@ constexpr int W3_V = 256 * 64 + 64 * 64 + 64;
 
 __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f, int nunits,
                                                    const float* __restrict__ bnc2, const float* __restrict__ coef,
-                                                   const unsigned char* __restrict__ arg, double* __restrict__ part) {
+                                                   const unsigned char* __restrict__ arg, double* __restrict__ part,
+                                                   const unsigned* __restrict__ a2amax) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int seA2 = h3_se_of(a2amax);                    // fp16x3 scale of a2 (both operands of the Gram)
+    const float sA2 = pow2_biased(seA2), GU = h3_unscale(seA2, seA2), iA2 = pow2_biased(254 - seA2);
     float4* tab = lds4;                                         // scale2, shift2: 2 x 16 float4
     float* comb = reinterpret_cast<float*>(lds4 + 32);          // [256][65] sparse dW3 combine (padded rows)
     float* gcomb = comb + 256 * 65;                             // [64][64] Gram combine
     float* scomb = gcomb + 64 * 64;                             // [64] sum a2
     float* T = scomb + 64 + (threadIdx.x >> 6) * (64 * TP);     // per-wave a2 tile; (256*65+4096+64)*4 B is 16-B aligned
-    if (threadIdx.x < 32) tab[threadIdx.x] = reinterpret_cast<const float4*>(bnc2 + 128)[threadIdx.x];
+    if (threadIdx.x < 32) {
+        float4 t = reinterpret_cast<const float4*>(bnc2 + 128)[threadIdx.x];
+        t.x *= sA2; t.y *= sA2; t.z *= sA2; t.w *= sA2;      // the tile holds a2 * sA2 (exact: a power of two); sums are scaled back below
+        tab[threadIdx.x] = t;
+    }
     __syncthreads();
     const float4* sc2 = tab; const float4* sh2 = tab + 16;
     const int lane = lane_id(), h = lane >> 5, q = lane & 31, wave = threadIdx.x >> 6;
@@ -400,8 +413,8 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
         for (int e = 0; e < 4; ++e) { cfv[e] = cfn[e]; psv[e] = psn[e]; }
         if (u + nwaves < nunits) issue_loads(u + nwaves);   // (unconditional, as in k_sa_fwd3_sb: measured 5 % slower here)
         WAVE_LDS_FENCE();
-        // Gram: G[i][j] += sum_p a2[p][i] a2[p][j] on fp16x3 (common.h; both operands are activations: fixed scale 2^4, the
-        // accumulators run at 2^8 and are scaled back when the waves are combined).  Operand fragments (lane = channel q of
+        // Gram: G[i][j] += sum_p a2[p][i] a2[p][j] on fp16x3 (common.h; both operands are activations at the scale of a2's bound,
+        // the accumulators are scaled back when the waves are combined).  Operand fragments (lane = channel q of
         // the tile, k-slots = positions 16 ks + 8 h + t) come out of the padded tile with 8 ds_read_b32 each -- the same 128
         // reads per unit the fp32 form issued -- and serve as A and as B operand alike; 36 MFMAs of 8 passes per unit instead
         // of 96 of 16 (ablation: the fp32 Gram was 0.115 of the pass's 0.37 ms).
@@ -418,8 +431,8 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
             for (int t = 0; t < 4; ++t) {
                 s2a += v0[2 * t] + v0[2 * t + 1];
                 s2b += v1[2 * t] + v1[2 * t + 1];
-                split_pair_h(v0[2 * t] * FACL_H3_SA, v0[2 * t + 1] * FACL_H3_SA, h0[t], l0[t]);
-                split_pair_h(v1[2 * t] * FACL_H3_SA, v1[2 * t + 1] * FACL_H3_SA, h1[t], l1[t]);
+                split_pair_h(v0[2 * t], v0[2 * t + 1], h0[t], l0[t]);
+                split_pair_h(v1[2 * t], v1[2 * t + 1], h1[t], l1[t]);
             }
             const f16x8h H0 = as_f16x8(h0[0], h0[1], h0[2], h0[3]), L0 = as_f16x8(l0[0], l0[1], l0[2], l0[3]);
             const f16x8h H1 = as_f16x8(h1[0], h1[1], h1[2], h1[3]), L1 = as_f16x8(l1[0], l1[1], l1[2], l1[3]);
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
 #pragma unroll
                 for (int k = 0; k < 64; ++k) {
                     float* d = &comb[(64 * e + lane) * 65 + k];
-                    *d = (w == 0 ? 0.f : *d) + accs[e][k];
+                    *d = (w == 0 ? 0.f : *d) + accs[e][k] * iA2;              // the tile rode at a2 * sA2: exact inverse
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -459,14 +472,13 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
                 float* d00 = &gcomb[i * 64 + q];
                 float* d01 = &gcomb[i * 64 + 32 + q];
                 float* d11 = &gcomb[(32 + i) * 64 + 32 + q];
-                constexpr float GU = 1.0f / (FACL_H3_SA * FACL_H3_SA);            // exact: 2^-8
                 *d00 = (w == 0 ? 0.f : *d00) + g00[r] * GU;
                 *d01 = (w == 0 ? 0.f : *d01) + g01[r] * GU;
                 *d11 = (w == 0 ? 0.f : *d11) + g11[r] * GU;
             }
             if (h == 0) {
-                scomb[q] = (w == 0 ? 0.f : scomb[q]) + s2ta;
-                scomb[32 + q] = (w == 0 ? 0.f : scomb[32 + q]) + s2tb;
+                scomb[q] = (w == 0 ? 0.f : scomb[q]) + s2ta * iA2;
+                scomb[32 + q] = (w == 0 ? 0.f : scomb[32 + q]) + s2tb * iA2;
             }
         }
         __syncthreads();
@@ -671,8 +683,8 @@ extern "C" int facl_sa_bwd0(const float* dpooled, const float* ymax, int64_t row
 
 extern "C" int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2, const float* G3, const float* h3,
                             const float* W3, const float* coef, const uint8_t* arg, float* dz2f, double* sums,
-                            void* ws, void* stream) {
-    if (!y2f || !bnc2 || !G3 || !h3 || !W3 || !coef || !arg || !dz2f || !sums || !ws) return FACL_E_NULL;
+                            void* ws, const uint32_t* a2amax, void* stream) {
+    if (!y2f || !bnc2 || !G3 || !h3 || !W3 || !coef || !arg || !dz2f || !sums || !ws || !a2amax) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
@@ -684,15 +696,15 @@ extern "C" int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2,
         attr_done = true;
     }
     hipLaunchKernelGGL(k_sa_bwd1, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, bnc2, G3, h3, W3, coef, arg, dz2f,
-                       (double*)ws);
+                       (double*)ws, a2amax);
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, grid * 4, 128, sums, st);
 }
 
 extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc2, const float* coef,
-                              const uint8_t* arg, double* out /* 20544 */, void* ws, void* stream) {
-    if (!y2f || !bnc2 || !coef || !arg || !out || !ws) return FACL_E_NULL;
+                              const uint8_t* arg, double* out /* 20544 */, void* ws, const uint32_t* a2amax, void* stream) {
+    if (!y2f || !bnc2 || !coef || !arg || !out || !ws || !a2amax) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
@@ -703,26 +715,26 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws);
+    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, a2amax);
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, grid, W3_V, out, st);
 }
 
 int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, int nunits, int D, const float* bw2,
-                           const float* W2, const float* l1tab, double* ws, int grid, hipStream_t st);   // sa_bwd2.hip
+                           const float* W2, const float* l1tab, double* ws, int grid, const uint32_t* a1amax, hipStream_t st);   // sa_bwd2.hip
 
 extern "C" int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nunits, int D,
                             const float* bw2, const float* W2, const float* l1tab, double* out /* 4608 */, void* ws,
-                            void* stream) {
-    if (!dz2f || !y2f || !x || !bw2 || !W2 || !l1tab || !out || !ws) return FACL_E_NULL;
+                            const uint32_t* a1amax, void* stream) {
+    if (!dz2f || !y2f || !x || !bw2 || !W2 || !l1tab || !out || !ws || !a1amax) return FACL_E_NULL;
     if ((D != 3 && D != 4) || nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     // FACL_BWD2_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one
     static const int use_f32 = getenv("FACL_BWD2_F32") ? atoi(getenv("FACL_BWD2_F32")) : 0;
     if (!use_f32) {
         const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 3) / 4 : 2 * SA_GRID);       // 2 workgroups of 4 waves per CU
-        int rc = facl_sa_bwd2_sb_launch(dz2f, y2f, x, (int)nunits, D, bw2, W2, l1tab, (double*)ws, grid, st);
+        int rc = facl_sa_bwd2_sb_launch(dz2f, y2f, x, (int)nunits, D, bw2, W2, l1tab, (double*)ws, grid, a1amax, st);
         if (rc) return rc;
         return facl_reduce_rows((const double*)ws, grid * 4, B2_V, out, st);
     }

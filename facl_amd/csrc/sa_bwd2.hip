@@ -56,7 +56,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const char* p_lo, const char* p_h
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// H3: fp16x3 arithmetic (common.h).  W2 by 2^8, a1 by 2^4 (fixed); dy2 -- a gradient, and computed here -- by the power of
+// H3: fp16x3 arithmetic (common.h).  W2 by the power of two of its own maximum, a1 by the one of its bound; dy2 -- a gradient, and computed here -- by the power of
 // two that puts the maximum of the wave's half unit in [2^13, 2^14) (one DPP reduction per half unit, no LDS, no host).  The
 // da1 tiles are scaled back when they are consumed; dW2's contribution of a half unit is accumulated in a temporary tile
 // and added to the running sums with the inverse scale, so half units of different magnitude mix exactly.
@@ -64,11 +64,16 @@ template <int D, bool H3>
 __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
     const float* __restrict__ dz2f, const float* __restrict__ y2f, const float* __restrict__ x, int nunits,
     const float* __restrict__ bw2 /* (4,64): scale2, A, B, mean2 */, const float* __restrict__ W2,
-    const float* __restrict__ l1tab_g, double* __restrict__ part, int rev) {
+    const float* __restrict__ l1tab_g, double* __restrict__ part, int rev, const unsigned* __restrict__ a1amax) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     uint4* w2p = reinterpret_cast<uint4*>(lds4);            // [(ct1*4 + kk)*3 + plane][lane]: 1536 uint4 = 24 KiB
     float4* tab = lds4 + 1536;                              // 4 x 16 float4
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // fp16x3 operand scales (common.h): W2 by the power of two of its own maximum (taken here; `tab` is filled further down),
+    // a1 by the one of the bound its forward used
+    int seW = 127, seA1 = 127;
+    if (H3) { seW = wg_h3_se(W2, 64 * 64, reinterpret_cast<float*>(tab)); seA1 = h3_se_of(a1amax); }
+    const float sW2 = pow2_biased(seW), sA1 = pow2_biased(seA1);
     float4* xs4 = tab + 64 + wave * 64;                     // per wave: x of the unit's 64 positions
     char* img = reinterpret_cast<char*>(tab + 64 + B2S_WAVES * 64) + wave * B2S_IMG;
     for (int i = threadIdx.x; i < 512; i += 64 * B2S_WAVES) {
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
         unsigned hi[4], mi[4], lo[4];
         if (H3) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { split_pair_h(v[2 * j] * FACL_H3_SW, v[2 * j + 1] * FACL_H3_SW, hi[j], mi[j]); lo[j] = 0u; }
+            for (int j = 0; j < 4; ++j) { split_pair_h(v[2 * j] * sW2, v[2 * j + 1] * sW2, hi[j], mi[j]); lo[j] = 0u; }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
@@ -176,11 +181,10 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                     }
                 }
                 mx = wave_max_nonneg(mx);
-                int se = 267 - (int)((__float_as_uint(mx) >> 23) & 0xff);      // 2^(13 - floor(log2 max)); NaN / inf pass through as such
-                se = se > 230 ? 230 : se;
-                const float sD = __uint_as_float((unsigned)se << 23);
-                uns_da = __uint_as_float((unsigned)(254 - se - 8) << 23);      // 1 / (sD 2^8)
-                uns_dw = __uint_as_float((unsigned)(254 - se - 4) << 23);      // 1 / (sD 2^4)
+                const int se = h3_se_wide(__float_as_uint(mx));                 // 2^(13 - floor(log2 max)); NaN / inf pass through as such
+                const float sD = pow2_biased(se);
+                uns_da = h3_unscale(se, seW);                                   // 1 / (sD sW2)
+                uns_dw = h3_unscale(se, seA1);                                  // 1 / (sD sA1)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int rt = kk >> 1, m = kk & 1;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                         unsigned hi[4], lo[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            split_pair_h(a1v[ct1][8 * s + 2 * j] * FACL_H3_SA, a1v[ct1][8 * s + 2 * j + 1] * FACL_H3_SA, hi[j], lo[j]);
+                            split_pair_h(a1v[ct1][8 * s + 2 * j] * sA1, a1v[ct1][8 * s + 2 * j + 1] * sA1, hi[j], lo[j]);
                         bx[s][ct1][0] = as_f16x8(hi[0], hi[1], hi[2], hi[3]);
                         bx[s][ct1][1] = as_f16x8(lo[0], lo[1], lo[2], lo[3]);
                     }
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
 
 // launcher for facl_sa_bwd2 (sa_bwd.hip): `grid` workgroups of B2S_WAVES waves, one partial row per wave in `ws`
 int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, int nunits, int D, const float* bw2,
-                           const float* W2, const float* l1tab, double* ws, int grid, hipStream_t st) {
+                           const float* W2, const float* l1tab, double* ws, int grid, const uint32_t* a1amax, hipStream_t st) {
     const size_t lds = (1536 + 64 + B2S_WAVES * 64) * sizeof(float4) + B2S_WAVES * (size_t)B2S_IMG;
     static bool attr_done = false;
     if (!attr_done) {
@@ -384,11 +388,11 @@ int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, 
     static const int h3 = getenv("FACL_BWD_H3") ? atoi(getenv("FACL_BWD_H3")) : 1;     // 0: bf16x6 (A/B)
     const dim3 g(grid), b(64 * B2S_WAVES);
     if (h3) {
-        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
-        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
+        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
     } else {
-        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, false>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
-        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, false>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev);
+        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, false>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
+        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, false>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
     }
     return facl_launch_status();
 }

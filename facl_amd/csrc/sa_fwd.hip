@@ -196,20 +196,25 @@ template <int D, bool H3>
 __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__ x, int nunits,
                                                        const float* __restrict__ l1tab_g, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, float* __restrict__ y2f,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, const unsigned* __restrict__ a1amax) {
     __shared__ uint4 w2p[2 * 4 * 3 * 64];   // A fragments of W2, [(rt*4 + kk)*3 + plane][lane]: W2[32rt+r][16kk+8h .. +7]
     __shared__ float4 l1tab[64 * 2];        // folded layer 1: [c][w0 w1 w2 w3 | b 0 0 0]
     __shared__ float4 b2s[16];
+    __shared__ float red[16];
+    // fp16x3 operand scales (common.h): W2 by the power of two of its own maximum (taken here), a1 by the one of its bound
+    int seW = 127, seA = 127;
+    if (H3) { seW = wg_h3_se(W2, 64 * 64, red); seA = h3_se_of(a1amax); }
+    const float sW = pow2_biased(seW), sA = pow2_biased(seA), sAW = sA * sW, unsAW = h3_unscale(seA, seW);
     for (int i = threadIdx.x; i < 512; i += 256) {
         const int ln = i & 63, kk = (i >> 6) & 3, rt = i >> 8;
         const float* wrow = W2 + (32 * rt + (ln & 31)) * 64 + 16 * kk + 8 * (ln >> 5);
         const float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 4);
         unsigned hi[4], mi[4], lo[4];
         if (H3) {                                            // fp16x3 (common.h): two fp16 planes of w * 2^8 in slots 0 and 1
-            split_pair_h(w0.x * FACL_H3_SW, w0.y * FACL_H3_SW, hi[0], mi[0]);
-            split_pair_h(w0.z * FACL_H3_SW, w0.w * FACL_H3_SW, hi[1], mi[1]);
-            split_pair_h(w1.x * FACL_H3_SW, w1.y * FACL_H3_SW, hi[2], mi[2]);
-            split_pair_h(w1.z * FACL_H3_SW, w1.w * FACL_H3_SW, hi[3], mi[3]);
+            split_pair_h(w0.x * sW, w0.y * sW, hi[0], mi[0]);
+            split_pair_h(w0.z * sW, w0.w * sW, hi[1], mi[1]);
+            split_pair_h(w1.x * sW, w1.y * sW, hi[2], mi[2]);
+            split_pair_h(w1.z * sW, w1.w * sW, hi[3], mi[3]);
             lo[0] = lo[1] = lo[2] = lo[3] = 0u;
         } else {
             split_pair(w0.x, w0.y, hi[0], mi[0], lo[0]);
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
     }
     if (threadIdx.x < 128) {
         float4 t = reinterpret_cast<const float4*>(l1tab_g)[threadIdx.x];
-        if (H3) { t.x *= FACL_H3_SA; t.y *= FACL_H3_SA; t.z *= FACL_H3_SA; t.w *= FACL_H3_SA; }   // relu(16 w.x + 16 b) = 16 relu(w.x + b): exact
+        if (H3) { t.x *= sA; t.y *= sA; t.z *= sA; t.w *= sA; }   // relu(s w.x + s b) = s relu(w.x + b) for a power of two s: exact
         l1tab[threadIdx.x] = t;
     }
     if (threadIdx.x < 16) b2s[threadIdx.x] = reinterpret_cast<const float4*>(b2)[threadIdx.x];
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 float4 bb = b2s[8 * rt + 2 * r4 + h];
-                if (H3) { bb.x *= 4096.f; bb.y *= 4096.f; bb.z *= 4096.f; bb.w *= 4096.f; }   // the accumulator runs at (a 2^4)(w 2^8)
+                if (H3) { bb.x *= sAW; bb.y *= sAW; bb.z *= sAW; bb.w *= sAW; }   // the accumulator runs at (a sA)(w sW)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     acc[rt][ct][4 * r4 + 0] = bb.x; acc[rt][ct][4 * r4 + 1] = bb.y;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_sa_fwd2_sb(const float* __restrict__
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rt][ct][r] *= FACL_H3_UNSCALE;
+                    for (int r = 0; r < 16; ++r) acc[rt][ct][r] *= unsAW;
         }
         float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
 #pragma unroll
@@ -522,7 +527,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                                                     const float* __restrict__ sc2, const float* __restrict__ sh2,
                                                     const float* __restrict__ W3, const float* __restrict__ b3,
                                                     const float* __restrict__ sgn3, float* __restrict__ ymax,
-                                                    unsigned char* __restrict__ arg, double* __restrict__ part) {
+                                                    unsigned char* __restrict__ arg, double* __restrict__ part,
+                                                    const unsigned* __restrict__ a2amax) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     uint4* w3p = reinterpret_cast<uint4*>(lds4);         // [(ct3*4 + kk)*3 + plane][lane]: 96 KiB
     float4* sc2s = lds4 + 6144;              // 16
@@ -530,6 +536,11 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
     float* b3s = reinterpret_cast<float*>(sh2s + 16);   // 256
     // per-wave fp64 (sum, sumsq) of y3 per channel: [ct3][q] (the two lane halves are merged before the update)
     double2* stat = reinterpret_cast<double2*>(b3s + 256) + (threadIdx.x >> 6) * 256;
+    // fp16x3 operand scales (common.h): W3 by the power of two of its own maximum (taken here; the statistics area is idle),
+    // a2 by the one of its bound
+    int seW = 127, seA = 127;
+    if (NP == 4) { seW = wg_h3_se(W3, 256 * 64, b3s); seA = h3_se_of(a2amax); }      // LDS scratch: b3s (filled further down)
+    const float sW3 = pow2_biased(seW), sA2 = pow2_biased(seA), UNS = h3_unscale(seA, seW);
     for (int i = threadIdx.x; i < 2048; i += 512) {
         const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
         const int c3 = 32 * ct3 + (ln & 31);
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         const float s = sgn_of(sgn3[c3]);
         unsigned hi[4], mi[4], lo[4];
         if (NP == 4) {                                      // fp16x3: two fp16 planes of w * 2^8 (plane slots 0 and 1)
-            const float sw = s * FACL_H3_SW;
+            const float sw = s * sW3;
             split_pair_h(w0.x * sw, w0.y * sw, hi[0], mi[0]);
             split_pair_h(w0.z * sw, w0.w * sw, hi[1], mi[1]);
             split_pair_h(w1.x * sw, w1.y * sw, hi[2], mi[2]);
@@ -564,8 +575,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
     if (threadIdx.x < 16) {
         float4 a = reinterpret_cast<const float4*>(sc2)[threadIdx.x], b = reinterpret_cast<const float4*>(sh2)[threadIdx.x];
         if (NP == 4) {                                       // relu(16 s y + 16 t) = 16 relu(s y + t) exactly: the activation scale is free
-            a.x *= FACL_H3_SA; a.y *= FACL_H3_SA; a.z *= FACL_H3_SA; a.w *= FACL_H3_SA;
-            b.x *= FACL_H3_SA; b.y *= FACL_H3_SA; b.z *= FACL_H3_SA; b.w *= FACL_H3_SA;
+            a.x *= sA2; a.y *= sA2; a.z *= sA2; a.w *= sA2;
+            b.x *= sA2; b.y *= sA2; b.z *= sA2; b.w *= sA2;
         }
         sc2s[threadIdx.x] = a;
         sh2s[threadIdx.x] = b;
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
                     const float4 y = yn[(ct * 2 + rt) * 4 + 2 * m + t];
                     const float4 sc = sc2s[8 * rt + 2 * (2 * m + t) + h], sh = sh2s[8 * rt + 2 * (2 * m + t) + h];
                     if (NP == 4) {
+                        // (fmaxf drops a NaN here; in training the layer's statistics -- sums of y2 taken by facl_sa_fwd2 -- carry it)
                         split_pair_h(fmaxf(fmaf(sc.x, y.x, sh.x), 0.f), fmaxf(fmaf(sc.y, y.y, sh.y), 0.f), hi[2 * t], mi[2 * t]);
                         split_pair_h(fmaxf(fmaf(sc.z, y.z, sh.z), 0.f), fmaxf(fmaf(sc.w, y.w, sh.w), 0.f), hi[2 * t + 1], mi[2 * t + 1]);
                         lo[2 * t] = lo[2 * t + 1] = 0u;
@@ -685,8 +697,8 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
             int bp = (int)(key & 63u);
             float s = s2.x + s2.y, sq = q2.x + q2.y;
             if (NP == 4) {                                      // exact rescale (powers of two); statistics stay those of u = y - bias
-                s *= FACL_H3_UNSCALE; sq *= FACL_H3_UNSCALE * FACL_H3_UNSCALE;
-                best = fmaf(best, FACL_H3_UNSCALE, b3s[32 * ct3 + q]);
+                s *= UNS; sq = (sq * UNS) * UNS;
+                best = fmaf(best, UNS, b3s[32 * ct3 + q]);
             }
             bp += 4 * h;
             return Epi{s, sq, best, bp};
@@ -739,19 +751,31 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
 }
 
 __global__ void k_sa_pool(const float* __restrict__ ymax, long long n4, int C4, const float* __restrict__ scale,
-                          const float* __restrict__ shift, float* __restrict__ pooled) {
+                          const float* __restrict__ shift, float* __restrict__ pooled, unsigned* __restrict__ amax) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int c4 = (int)(i % C4);
         const float4 y = reinterpret_cast<const float4*>(ymax)[i];
         const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
         const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
         float4 o;
-        o.x = fmaxf(fmaf(fabsf(sc.x), y.x, sh.x), 0.f);
-        o.y = fmaxf(fmaf(fabsf(sc.y), y.y, sh.y), 0.f);
-        o.z = fmaxf(fmaf(fabsf(sc.z), y.z, sh.z), 0.f);
-        o.w = fmaxf(fmaf(fabsf(sc.w), y.w, sh.w), 0.f);
+        o.x = relu_nan(fmaf(fabsf(sc.x), y.x, sh.x));
+        o.y = relu_nan(fmaf(fabsf(sc.y), y.y, sh.y));
+        o.z = relu_nan(fmaf(fabsf(sc.z), y.z, sh.z));
+        o.w = relu_nan(fmaf(fabsf(sc.w), y.w, sh.w));
         reinterpret_cast<float4*>(pooled)[i] = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));
+    }
+    // the exact maximum of the pooled features (>= 0) for the fp16x3 scale of the GEMM that consumes them: one atomic per
+    // wave into one of the FACL_AMAX_SLOTS hashed slots (non-negative floats order like unsigned integers)
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+            atomicMax(amax + (wave & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE, __float_as_uint(mx));
+        }
     }
 }
 
@@ -769,9 +793,10 @@ extern "C" int facl_sa_x_moments(const float* x, int64_t P, int D, double* mom, 
     return facl_reduce_rows((const double*)ws, grid * 4, V, mom, st);
 }
 
+// a1amax: FACL_AMAX_WORDS uint32 holding the bits of a bound of max|a1| (facl_sa_l1tab writes it): the fp16x3 scale of a1
 extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* l1tab, const float* W2,
-                            const float* b2, float* y2f, double* sums2, void* ws, void* stream) {
-    if (!x || !l1tab || !W2 || !b2 || !y2f || (sums2 && !ws)) return FACL_E_NULL;
+                            const float* b2, float* y2f, double* sums2, void* ws, const uint32_t* a1amax, void* stream) {
+    if (!x || !l1tab || !W2 || !b2 || !y2f || (sums2 && !ws) || !a1amax) return FACL_E_NULL;
     if ((D != 3 && D != 4) || nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < 2 * SA_GRID * 4 ? (nunits + 3) / 4 : 2 * SA_GRID);   // 2 workgroups per CU
@@ -784,11 +809,11 @@ extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* 
         // fp16x3 (two fp16 planes, three products: csrc/common.h) unless FACL_FWD_H3=0 selects bf16x6 (A/B)
         static const int h3 = getenv("FACL_FWD_H3") ? atoi(getenv("FACL_FWD_H3")) : 1;
         if (h3) {
-            if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4, true>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
-            else hipLaunchKernelGGL((k_sa_fwd2_sb<3, true>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+            if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4, true>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part, a1amax);
+            else hipLaunchKernelGGL((k_sa_fwd2_sb<3, true>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part, a1amax);
         } else {
-            if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4, false>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
-            else hipLaunchKernelGGL((k_sa_fwd2_sb<3, false>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part);
+            if (D == 4) hipLaunchKernelGGL((k_sa_fwd2_sb<4, false>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part, a1amax);
+            else hipLaunchKernelGGL((k_sa_fwd2_sb<3, false>), dim3(grid), dim3(256), 0, st, x, (int)nunits, l1tab, W2, b2, y2f, part, a1amax);
         }
     }
     int rc = facl_launch_status();
@@ -799,8 +824,8 @@ extern "C" int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* 
 
 static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
                      const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
-                     double* sums3, void* ws, void* stream, int prec) {
-    if (!y2f || !scale2 || !shift2 || !W3 || !b3 || !sgn3 || !ymax || !arg || (sums3 && !ws)) return FACL_E_NULL;
+                     double* sums3, void* ws, void* stream, int prec, const uint32_t* a2amax = nullptr) {
+    if (!y2f || !scale2 || !shift2 || !W3 || !b3 || !sgn3 || !ymax || !arg || (sums3 && !ws) || (prec == 3 && !a2amax)) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 7) / 8 : SA_GRID);
@@ -824,16 +849,16 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
                            arg, part);
     else if (prec == 1)
         hipLaunchKernelGGL((k_sa_fwd3_sb<1>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
-                           ymax, arg, part);
+                           ymax, arg, part, a2amax);
     else if (prec == 2)
         hipLaunchKernelGGL((k_sa_fwd3_sb<2>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
-                           ymax, arg, part);
+                           ymax, arg, part, a2amax);
     else if (prec == 3)
         hipLaunchKernelGGL((k_sa_fwd3_sb<4>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
-                           ymax, arg, part);
+                           ymax, arg, part, a2amax);
     else
         hipLaunchKernelGGL((k_sa_fwd3_sb<3>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
-                           ymax, arg, part);
+                           ymax, arg, part, a2amax);
     int rc = facl_launch_status();
     if (rc || !sums3) return rc;
     return facl_reduce_rows(part, grid * 8, 512, sums3, st);
@@ -855,8 +880,8 @@ extern "C" int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* s
 // accumulation -- fp32-GEMM accuracy at half the MFMA work of facl_sa_fwd3; the default forward arithmetic of the model
 extern "C" int facl_sa_fwd3_h3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
                                const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
-                               void* stream) {
-    return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 3);
+                               const uint32_t* a2amax, void* stream) {
+    return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 3, a2amax);
 }
 
 // "bf16x3" twin (opt-in precision "x3")
@@ -866,12 +891,13 @@ extern "C" int facl_sa_fwd3_x3(const float* y2f, int64_t nunits, const float* sc
     return sa_fwd3_p(y2f, nunits, scale2, shift2, W3, b3, sgn3, ymax, arg, sums3, ws, stream, 2);
 }
 
+// amax (or null): FACL_AMAX_WORDS uint32, zeroed or holding earlier maxima; raised to the bits of max(pooled)
 extern "C" int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
-                            float* pooled, void* stream) {
+                            float* pooled, uint32_t* amax, void* stream) {
     if (!ymax || !scale || !shift || !pooled) return FACL_E_NULL;
     if (rows < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
     const long long n4 = rows * (long long)(C / 4);
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_sa_pool, dim3(grid), dim3(256), 0, (hipStream_t)stream, ymax, n4, C / 4, scale, shift, pooled);
+    hipLaunchKernelGGL(k_sa_pool, dim3(grid), dim3(256), 0, (hipStream_t)stream, ymax, n4, C / 4, scale, shift, pooled, amax);
     return facl_launch_status();
 }

@@ -32,13 +32,38 @@ class _Workspace:
         return cls._ws[key]
 
 
-def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM):
+def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, aamax=None):
+    """`aamax` (one row of _lib.amax_buffers): receives the bound of the layer's activation, the fp16x3 scale of the GEMM that
+    consumes it (|gamma| sqrt(count - 1) sigma invstd + |beta|: csrc/finalize.hip)."""
     lib = _lib.load_library()
     bnc = _lib.empty((5, C), dtype=torch.float32, device=sums.device)
     _lib.check(lib.facl_bn_finalize(_lib.ptr(sums), C, float(count), _lib.ptr(gamma), _lib.ptr(beta), BN_EPS,
                                     momentum, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(bnc),
-                                    _lib.stream()), "facl_bn_finalize")
+                                    _lib.ptr(aamax), _lib.stream()), "facl_bn_finalize")
     return bnc
+
+
+def act_amax_eval(y_rows, bnc, aamax):
+    """Eval mode: running statistics say nothing about the data, so the activation maximum max relu(scale y + shift) is
+    MEASURED (one streaming pass over the layer's raw output) into `aamax`."""
+    lib = _lib.load_library()
+    R, C = y_rows.shape
+    _lib.check(lib.facl_rows_act_amax(_lib.ptr(y_rows), R, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(aamax), _lib.stream()),
+               "facl_rows_act_amax")
+
+
+_FRAG_ORDER = {}
+
+
+def _frag_channel_order(dev):
+    """Channel of every float of ONE position-pair... of a unit tile in the fragment layout (csrc/common.h), as a (4096,) index
+    tensor: element ((ct*2 + rt)*4 + r4)*256 + lane*4 + e holds channel 32 rt + 8 r4 + 4 (lane >> 5) + e."""
+    key = (dev.type, dev.index)
+    if key not in _FRAG_ORDER:
+        i = torch.arange(4096, device=dev)
+        e, lane, r4, rt = i & 3, (i >> 2) & 63, (i >> 8) & 3, (i >> 10) & 1
+        _FRAG_ORDER[key] = 32 * rt + 8 * r4 + 4 * (lane >> 5) + e
+    return _FRAG_ORDER[key]
 
 
 def _bn_eval(C, gamma, beta, running_mean, running_var):
@@ -99,6 +124,8 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     W2 = p["W2"].reshape(64, 64)
     W3 = p["W3"].reshape(256, 64)
     ctx = {}
+    # fp16x3 operand maxima (csrc/common.h): [0] max|x| (eval), [1] bound of a1, [2] bound of a2, [3] max(pooled)
+    amax = _lib.amax_buffers(4, dev)
     if training:
         mom = _lib.empty(D + D * D, **f64)
         _lib.check(lib.facl_sa_x_moments(_lib.ptr(x_rows), P, D, _lib.ptr(mom), _lib.ptr(ws), st), "facl_sa_x_moments")
@@ -112,29 +139,39 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         direct = update_running and rep == 1
         n_true = count / rep
         rm, rv = (p["rm1"], p["rv1"]) if direct else (None, None)
-        bnc1 = _bn_finalize(sums1, 64, count, p["g1"], p["be1"], rm, rv)
+        bnc1 = _bn_finalize(sums1, 64, count, p["g1"], p["be1"], rm, rv, aamax=amax[1])
         if update_running and not direct:
             _running_update(bnc1, p["rm1"], p["rv1"], n_true)
         ctx["mom"] = mom
+        xa = None
     else:
         bnc1 = _bn_eval(64, p["g1"], p["be1"], p["rm1"], p["rv1"])
+        xa = amax[0]                                       # eval: the bound of a1 follows from max|x| (facl_sa_l1tab)
+        _lib.check(lib.facl_absmax(_lib.ptr(x_rows), x_rows.numel(), _lib.ptr(xa), st), "facl_absmax")
     l1tab = _lib.empty((64, 8), dtype=torch.float32, device=dev)
     _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(p["b1"]), D, _lib.ptr(bnc1[2]), _lib.ptr(bnc1[3]),
-                                 _lib.ptr(l1tab), st), "facl_sa_l1tab")
+                                 _lib.ptr(l1tab), _lib.ptr(xa), None if xa is None else _lib.ptr(amax[1]), st), "facl_sa_l1tab")
     y2f = _lib.empty(nunits * UNIT * 64, dtype=torch.float32, device=dev)
     sums2 = _lib.empty((64, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd2"):
         _lib.check(lib.facl_sa_fwd2(_lib.ptr(x_rows), nunits, D, _lib.ptr(l1tab), _lib.ptr(W2), _lib.ptr(p["b2"]),
-                                    _lib.ptr(y2f), _lib.ptr(sums2), _lib.ptr(ws), st), "facl_sa_fwd2")
+                                    _lib.ptr(y2f), _lib.ptr(sums2), _lib.ptr(ws), _lib.ptr(amax[1]), st), "facl_sa_fwd2")
     if training:
         if reduce_fn is not None:
             reduce_fn(sums2)
         rm, rv = (p["rm2"], p["rv2"]) if direct else (None, None)
-        bnc2 = _bn_finalize(sums2, 64, count, p["g2"], p["be2"], rm, rv)
+        bnc2 = _bn_finalize(sums2, 64, count, p["g2"], p["be2"], rm, rv, aamax=amax[2])
         if update_running and not direct:
             _running_update(bnc2, p["rm2"], p["rv2"], n_true)
     else:
         bnc2 = _bn_eval(64, p["g2"], p["be2"], p["rm2"], p["rv2"])
+        # eval: measured maximum of a2.  The fragment layout keeps 4 consecutive channels per float4 and the 64 channels of a
+        # position in 16 float4s whose channel base is a function of the float4's index alone -- the row kernel only needs the
+        # per-float4 constants in that order
+        lay = _frag_channel_order(dev)
+        sc_l, sh_l = bnc2[2][lay].contiguous(), bnc2[3][lay].contiguous()
+        _lib.check(lib.facl_rows_act_amax(_lib.ptr(y2f), nunits, 4096, _lib.ptr(sc_l), _lib.ptr(sh_l), _lib.ptr(amax[2]), st),
+                   "facl_rows_act_amax")
     sgn3 = p["g3"]                                                    # the kernels take sign(gamma3) themselves (sign(0) = +1)
     ymax = _lib.empty((nunits, 256), dtype=torch.float32, device=dev)
     arg = _lib.empty((nunits, 256), dtype=torch.uint8, device=dev)
@@ -144,9 +181,10 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         # "f32" / "x3b": the fp32-grade forward -- fp16x3 (csrc/common.h; FACL_FWD_H3=0 selects bf16x6 for A/B)
         f32_fwd3 = lib.facl_sa_fwd3_h3 if _FWD_H3 else lib.facl_sa_fwd3
         fwd3 = {"f32": f32_fwd3, "f16": lib.facl_sa_fwd3_f16, "x3": lib.facl_sa_fwd3_x3, "x3b": f32_fwd3}[precision]
+        extra = (_lib.ptr(amax[2]),) if fwd3 is lib.facl_sa_fwd3_h3 else ()
         _lib.check(fwd3(_lib.ptr(y2f), nunits, _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3),
                                     _lib.ptr(p["b3"]), _lib.ptr(sgn3), _lib.ptr(ymax), _lib.ptr(arg), _lib.ptr(sums3),
-                                    _lib.ptr(ws), st), "facl_sa_fwd3")
+                                    _lib.ptr(ws), *extra, st), "facl_sa_fwd3")
     _lib.tap("sa_arg", arg)
     if training:
         if reduce_fn is not None:
@@ -163,8 +201,8 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         ymax_g, rsel = ymax.view(ngroups, R, 256).max(dim=1)
         ymax_g = ymax_g.contiguous()
     pooled = _lib.empty((ngroups, 256), dtype=torch.float32, device=dev)
-    _lib.check(lib.facl_sa_pool(_lib.ptr(ymax_g), ngroups, 256, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(pooled), st),
-               "facl_sa_pool")
+    _lib.check(lib.facl_sa_pool(_lib.ptr(ymax_g), ngroups, 256, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(pooled),
+                                _lib.ptr(amax[3]), st), "facl_sa_pool")
     if _lib.TAPS is not None and K == UNIT:          # tests only: the ReLU decisions of the three layers (tie-proof parity)
         xd, tb = x_rows.double(), l1tab.double()
         v = (tb[:, 0] * xd[:, :1] + tb[:, 4]).float().double()                # the kernels' sequential fp32 FMA chain
@@ -174,6 +212,7 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         y2n = y2f.view(nunits, 2, 2, 4, 2, 32, 4).permute(0, 1, 5, 2, 3, 4, 6).reshape(nunits * UNIT, 64)   # fragment layout -> (P, 64)
         _lib.tap_relu("relu_sa2", y2n, bnc2[2], bnc2[3])
         _lib.tap_relu("relu_sa3", a=pooled)
+    ctx["amax"] = amax                               # [1], [2]: the backward's operand scales; [3]: max(pooled) for the next GEMM
     ctx.update(y2f=y2f, ymax=ymax_g, arg=arg, bnc1=bnc1, bnc2=bnc2, bnc3=bnc3, sgn3=sgn3, l1tab=l1tab, count=count,
                nunits=nunits, D=D, R=R, rsel=rsel, ngroups=ngroups, x_rows=x_rows)
     return pooled, ctx
@@ -226,7 +265,7 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     sums1 = _lib.empty((64, 2), **f64)
     with _lib.timed("facl_sa_bwd1"):
         _lib.check(lib.facl_sa_bwd1(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(G3), ptr(h3), ptr(W3), ptr(coef),
-                                    ptr(ctx["arg"]), ptr(dz2f), ptr(sums1), ptr(ws), st), "facl_sa_bwd1")
+                                    ptr(ctx["arg"]), ptr(dz2f), ptr(sums1), ptr(ws), ptr(ctx["amax"][2]), st), "facl_sa_bwd1")
     sums1_l = sums1
     if reduce_fn is not None:
         sums1 = reduce_fn(sums1.clone())
@@ -238,12 +277,12 @@ def _sa_mlp_backward(ctx, dpooled, x_rows, p, reduce_fn=None):
     out2 = _lib.empty(64 * 64 + 8 * 64, **f64)
     with _lib.timed("facl_sa_bwd2"):
         _lib.check(lib.facl_sa_bwd2(ptr(dz2f), ptr(ctx["y2f"]), ptr(x_rows), nunits, D, ptr(bw2), ptr(W2), ptr(ctx["l1tab"]),
-                                    ptr(out2), ptr(ws), st), "facl_sa_bwd2")
+                                    ptr(out2), ptr(ws), ptr(ctx["amax"][1]), st), "facl_sa_bwd2")
     # ---- layer-3 weight gradient ingredients: sparse gather, Gram, sum a2
     out3 = _lib.empty(256 * 64 + 64 * 64 + 64, **f64)
     with _lib.timed("facl_sa_bwd_w3"):
-        _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws), st),
-                   "facl_sa_bwd_w3")
+        _lib.check(lib.facl_sa_bwd_w3(ptr(ctx["y2f"]), nunits, ptr(bnc2), ptr(coef), ptr(ctx["arg"]), ptr(out3), ptr(ws),
+                                      ptr(ctx["amax"][2]), st), "facl_sa_bwd_w3")
 
     R1_g = out2[4096:]
     if reduce_fn is not None:
@@ -274,6 +313,7 @@ class SAMLPFunction(torch.autograd.Function):
         p.update(state["buffers"])
         pooled, c = sa_mlp_forward(x_rows, p, state["training"], state.get("reduce_fn"), K=state.get("K", UNIT),
                                    precision=state.get("precision", "f32"))
+        state["pooled_amax"] = c["amax"][3]               # max(pooled): the fp16x3 scale of the GEMM that consumes the features
         ctx.c, ctx.p, ctx.x_rows, ctx.reduce_fn = c, p, x_rows, state.get("reduce_fn")
         ctx.training = state["training"]
         return pooled

@@ -10,7 +10,7 @@ import threading
 import torch
 
 from . import _lib
-from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize
+from .sa_mlp import BN_EPS, BN_MOMENTUM, _Workspace, _bn_eval, _bn_finalize, act_amax_eval
 
 
 # ---- arithmetic of the dense contractions -------------------------------------------------------------------------------
@@ -91,9 +91,10 @@ def gemm_dgrad(dy, W, prec=None):
     return da
 
 
-def gemm_wgrad(dy, a, prec=None, amax=None):
+def gemm_wgrad(dy, a, prec=None, amax=None, amax_b=None):
     """dW = dy^T a, contraction over the rows split into slices (deterministic slice-order sum).  `amax` (the device-side
-    max|dy| buffer of facl_rows_bwd_apply_amax): fp16x3 arithmetic where the 128x128-tile kernel serves the shape."""
+    max|dy| buffer of facl_rows_bwd_apply_amax) + `amax_b` (the bound of max|a| its forward GEMM used): fp16x3 arithmetic
+    where the 128x128-tile kernel serves the shape."""
     lib = _lib.load_library()
     M, N = dy.shape
     K = a.shape[1]
@@ -102,10 +103,10 @@ def gemm_wgrad(dy, a, prec=None, amax=None):
     dW = _lib.empty((N, K), dtype=torch.float32, device=dy.device)
     slices = _lib.empty(nz * N * K, dtype=torch.float32, device=dy.device)
     prec = current_precision() if prec is None else prec
-    if amax is not None and prec == "f32":
+    if amax is not None and amax_b is not None and prec == "f32":
         with _lib.timed("facl_gemm_wgrad %dx%dx%d h3" % (M, N, K)):
-            rc = lib.facl_gemm_wgrad_h3(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), None, None, _lib.ptr(amax), _lib.ptr(dW),
-                                        _lib.ptr(slices), nz, _lib.stream())
+            rc = lib.facl_gemm_wgrad_h3(_lib.ptr(dy), _lib.ptr(a), M, N, K, a.stride(0), None, None, _lib.ptr(amax), _lib.ptr(amax_b),
+                                        _lib.ptr(dW), _lib.ptr(slices), nz, _lib.stream())
         if rc != -4:
             _lib.check(rc, "facl_gemm_wgrad_h3")
             return dW
@@ -134,18 +135,22 @@ def _bn_bwd_consts(sums, C, count, reduce_fn):
     return dbeta, dgamma, kk
 
 
-def _forward_bn_consts(y, bn, training, reduce_fn, ws, sums=None):
-    """Statistics -> (5,C) constants; updates running stats / num_batches_tracked in training mode."""
+def _forward_bn_consts(y, bn, training, reduce_fn, ws, sums=None, aamax=None):
+    """Statistics -> (5,C) constants; updates running stats / num_batches_tracked in training mode.  `aamax` (optional):
+    receives the bound (training: BatchNorm's own; eval: measured) of the layer's activation for the fp16x3 GEMM behind it."""
     R, C = y.shape
     if not training:
-        return _bn_eval(C, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var), float(R)
+        bnc = _bn_eval(C, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
+        if aamax is not None:
+            act_amax_eval(y, bnc, aamax)
+        return bnc, float(R)
     if sums is None:
         sums = _stats(y, ws)
     count = float(R)
     if reduce_fn is not None:
         reduce_fn(sums)
         count = count * reduce_fn.world_size                  # equal shards (no host round trip for the count)
-    bnc = _bn_finalize(sums, C, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
+    bnc = _bn_finalize(sums, C, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, aamax=aamax)
     bn.count_batch()
     return bnc, count
 
@@ -237,7 +242,7 @@ class _LinearBNSegmax(torch.autograd.Function):
             if rc == 0:
                 fused = True
                 bnc, count = _forward_bn_consts(y, bn, training, reduce_fn, ws, sums)
-                _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(xpre),
+                _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]), _lib.ptr(xpre), None,
                                             _lib.stream()), "facl_sa_pool")
             elif rc != -4:                                   # FACL_E_CONFIG: too small for the fused kernel
                 _lib.check(rc, "facl_gemm_fwd_segmax")
@@ -531,7 +536,7 @@ FWD_H3 = __import__("os").environ.get("FACL_FWD_H3", "1") != "0"
 BWD_H3 = __import__("os").environ.get("FACL_BWD_H3", "1") != "0"
 
 
-def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws, half=False):
+def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws, half=False, amax_a=None):
     lib = _lib.load_library()
     M, K = a.shape
     y = _lib.empty((M, N), dtype=torch.float32, device=a.device)
@@ -542,7 +547,7 @@ def _rs_fwd(a, planes, N, bias, pro, centers, want_stats, seg_sgn, ws, half=Fals
         arg = _lib.empty((M // 64, N), dtype=torch.int32, device=a.device)
     ps, pt = (pro[2], pro[3]) if pro is not None else (None, None)
     with _lib.timed("facl_gemm_rs_fwd %dx%dx%d%s" % (M, K, N, " h3" if half else "")):
-        _lib.check(lib.facl_gemm_rs_fwd(_lib.ptr(a), M, K, _lib.ptr(planes), 1 if half else 0, N, _lib.ptr(bias), _lib.ptr(ps), _lib.ptr(pt),
+        _lib.check(lib.facl_gemm_rs_fwd(_lib.ptr(a), M, K, _lib.ptr(planes), 1 if half else 0, _lib.ptr(amax_a), N, _lib.ptr(bias), _lib.ptr(ps), _lib.ptr(pt),
                                         _lib.ptr(centers), _lib.ptr(y), _lib.ptr(sums), _lib.ptr(seg_sgn), _lib.ptr(ymax),
                                         _lib.ptr(arg), _lib.ptr(ws), _lib.stream()), "facl_gemm_rs_fwd")
     return y, sums, ymax, arg
@@ -580,9 +585,10 @@ def _rs_dgrad(dy, W, prec, planes=None, bn_y=None, bn_c=None, ws=None, amax=None
 _WGRAD_RS = __import__("os").environ.get("FACL_WGRAD_RS", "1") != "0"            # A/B switch
 
 
-def _wgrad_pro(dy, y, bnc, prec, amax=None):
+def _wgrad_pro(dy, y, bnc, prec, amax=None, amax_b=None):
     """dW = dy^T relu(bn(y)) with the activation recomputed while staged; falls back to a materialised activation.
-    `amax`: bits of max|dy| (device scalar) -> fp16x3 arithmetic where the register-streamed kernel serves the shape."""
+    `amax`: bits of max|dy|, `amax_b`: the bound of max relu(bn(y)) the forward used -> fp16x3 arithmetic where the
+    register-streamed kernel serves the shape."""
     lib = _lib.load_library()
     M, N = dy.shape
     K = y.shape[1]
@@ -592,7 +598,8 @@ def _wgrad_pro(dy, y, bnc, prec, amax=None):
         slices = _lib.empty(nzr * N * K, dtype=torch.float32, device=dy.device)
         with _lib.timed("facl_gemm_rs_wgrad %dx%dx%d%s" % (M, N, K, "" if amax is None else " h3")):
             _lib.check(lib.facl_gemm_rs_wgrad(_lib.ptr(dy), _lib.ptr(y), M, N, K, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
-                                              _lib.ptr(amax), _lib.ptr(dW), _lib.ptr(slices), _lib.stream()), "facl_gemm_rs_wgrad")
+                                              _lib.ptr(amax), _lib.ptr(amax_b), _lib.ptr(dW), _lib.ptr(slices), _lib.stream()),
+                       "facl_gemm_rs_wgrad")
         return dW
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     nz = max(1, min((M + 255) // 256, 512 // tiles))
@@ -600,7 +607,7 @@ def _wgrad_pro(dy, y, bnc, prec, amax=None):
     if amax is not None and prec == "f32":                              # fp16x3 on the LDS-staged kernel (the narrower layers)
         with _lib.timed("facl_gemm_wgrad %dx%dx%d h3" % (M, N, K)):
             rc = lib.facl_gemm_wgrad_h3(_lib.ptr(dy), _lib.ptr(y), M, N, K, y.stride(0), _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
-                                        _lib.ptr(amax), _lib.ptr(dW), _lib.ptr(slices), nz, _lib.stream())
+                                        _lib.ptr(amax), _lib.ptr(amax_b), _lib.ptr(dW), _lib.ptr(slices), nz, _lib.stream())
         if rc != -4:
             _lib.check(rc, "facl_gemm_wgrad_h3")
             return dW
@@ -636,7 +643,7 @@ class _Net3DV3(torch.autograd.Function):
     activation operand is recomputed from the raw layer output while it is staged."""
 
     @staticmethod
-    def forward(ctx, pooled, centers, S, training, reduce_fn, bns, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3):
+    def forward(ctx, pooled, centers, S, training, reduce_fn, bns, pooled_amax, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3):
         ctx.prec = current_precision()
         lib = _lib.load_library()
         _lib.require_cuda(pooled)
@@ -654,15 +661,25 @@ class _Net3DV3(torch.autograd.Function):
         pl = rs_planes_multi(jobs)
         ctx.bwd_planes = pl[3:] if want_bwd else None
         ctx.bwd_h3 = want_bwd and BWD_H3
-        y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws, h3)
-        bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1)
-        y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws, h3)
-        bnc2, _ = _forward_bn_consts(y2, bns[1], training, reduce_fn, ws, sums2)
-        y3, sums3, ymax, arg = _rs_fwd(y2, pl[2], W3.shape[0], b3, bnc2, None, training, g3.detach(), ws, h3)
+        # fp16x3 operand maxima of the three row operands (csrc/common.h): [0] max(pooled, |centres|) -- the pooled features
+        # bring their exact maximum from facl_sa_pool when the caller hands it over --, [1] / [2] the bounds of a1 / a2
+        amax = _lib.amax_buffers(3, pooled.device)
+        if pooled_amax is not None:
+            a0 = pooled_amax
+        else:
+            a0 = amax[0]
+            _lib.check(lib.facl_absmax(_lib.ptr(pooled), pooled.numel(), _lib.ptr(a0), _lib.stream()), "facl_absmax")
+        _lib.check(lib.facl_absmax(_lib.ptr(centers), centers.numel(), _lib.ptr(a0), _lib.stream()), "facl_absmax")
+        y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws, h3, a0)
+        bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1, aamax=amax[1])
+        y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws, h3, amax[1])
+        bnc2, _ = _forward_bn_consts(y2, bns[1], training, reduce_fn, ws, sums2, aamax=amax[2])
+        y3, sums3, ymax, arg = _rs_fwd(y2, pl[2], W3.shape[0], b3, bnc2, None, training, g3.detach(), ws, h3, amax[2])
+        ctx.act_amax = (a0, amax[1], amax[2])
         bnc3, _ = _forward_bn_consts(y3, bns[2], training, reduce_fn, ws, sums3)
         M, C = P // S, W3.shape[0]
         xpre = _lib.empty((M, C), dtype=torch.float32, device=pooled.device)
-        _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(xpre), _lib.stream()),
+        _lib.check(lib.facl_sa_pool(_lib.ptr(ymax), M, C, _lib.ptr(bnc3[2]), _lib.ptr(bnc3[3]), _lib.ptr(xpre), None, _lib.stream()),
                    "facl_sa_pool")
         _lib.tap("seg_arg", arg)
         _lib.tap_relu("relu_t1", y1, bnc1[2], bnc1[3])
@@ -700,7 +717,8 @@ class _Net3DV3(torch.autograd.Function):
                                                   _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), _lib.ptr(am(0)), st),
                    "facl_segmax_bwd_apply")
         bpl = ctx.bwd_planes if ctx.bwd_planes is not None else (None, None, None)
-        dW3 = _wgrad_pro(dy, y2, bnc2, bp, am(0))
+        a0b, a1b, a2b = ctx.act_amax                       # the activation bounds the forward GEMMs used
+        dW3 = _wgrad_pro(dy, y2, bnc2, bp, am(0), a2b)
         # dgrad + the statistics pass of the next BatchNorm backward in one kernel (the tile is still in registers)
         da, sums = _rs_dgrad(dy, W3, bp, bpl[0], y2, bnc2, ws, am(0))
         # ---- layers 2 and 1: BN backward rows passes, weight gradient with the recomputed activation, dgrad
@@ -716,10 +734,10 @@ class _Net3DV3(torch.autograd.Function):
             _lib.check(lib.facl_rows_bwd_apply_amax(_lib.ptr(da), _lib.ptr(y), P, C, _lib.ptr(bnc), _lib.ptr(kk), _lib.ptr(dy),
                                                     _lib.ptr(am(li)), st), "facl_rows_bwd_apply")
             if yin is not None:
-                dW = _wgrad_pro(dy, yin, bnc_in, bp, am(li))
+                dW = _wgrad_pro(dy, yin, bnc_in, bp, am(li), a1b)
                 da, sums = _rs_dgrad(dy, W, bp, bpl[1], yin, bnc_in, ws, am(li))
             else:                                                       # first layer: input = pooled | centres
-                dWh = gemm_wgrad(dy, pooled, prec=bp, amax=am(li))
+                dWh = gemm_wgrad(dy, pooled, prec=bp, amax=am(li), amax_b=a0b)
                 dWc = _lib.empty((C, 3), **f64)
                 _lib.check(lib.facl_rows_center_wgrad(_lib.ptr(dy), _lib.ptr(centers), P, C, _lib.ptr(dWc), _lib.ptr(ws), st),
                            "facl_rows_center_wgrad")
@@ -728,13 +746,14 @@ class _Net3DV3(torch.autograd.Function):
             grads.append((dW, dga, dbe))
         (dW2, dga2, dbe2), (dW1, dga1, dbe1) = grads
         # d(bias) of a conv in front of a train-mode BN is identically zero: None leaves the parameter untouched
-        return (da, None, None, None, None, None, dW1, None, dga1, dbe1, dW2, None, dga2, dbe2, dW3, None, dga3, dbe3)
+        return (da, None, None, None, None, None, None, dW1, None, dga1, dbe1, dW2, None, dga2, dbe2, dW3, None, dga3, dbe3)
 
 
-def net3dv3(pooled, centers, net, training, S, reduce_fn=None):
-    """`net` = the nn.Sequential-like net3DV_3 container (indices 0,1 / 3,4 / 6,7 = affine, BatchNorm of the three layers)."""
+def net3dv3(pooled, centers, net, training, S, reduce_fn=None, pooled_amax=None):
+    """`net` = the nn.Sequential-like net3DV_3 container (indices 0,1 / 3,4 / 6,7 = affine, BatchNorm of the three layers).
+    `pooled_amax`: the _lib.amax_buffers row facl_sa_pool raised to max(pooled) (else it is measured here)."""
     view = lambda a: a.weight.view(a.weight.shape[0], -1)
-    return _Net3DV3.apply(pooled, centers, S, training, reduce_fn, (net[1], net[4], net[7]),
+    return _Net3DV3.apply(pooled, centers, S, training, reduce_fn, (net[1], net[4], net[7]), pooled_amax,
                           view(net[0]), net[0].bias, net[1].weight, net[1].bias,
                           view(net[3]), net[3].bias, net[4].weight, net[4].bias,
                           view(net[6]), net[6].bias, net[7].weight, net[7].bias)

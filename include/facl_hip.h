@@ -78,9 +78,12 @@ int facl_group_clips(const float* clips, int B, int G, int N, int D, int S, int 
  * running_mean / running_var (may both be NULL) are updated in place with `momentum` and the
  * unbiased variance, like F.batch_norm(training=True). */
 int64_t facl_ws_bytes(void);   /* size of the scratch buffer `ws` the reducing calls need */
+/* aamax (or NULL): FACL_AMAX_WORDS uint32 that receive (in every slot) the bits of a rigorous BOUND of the layer's activation
+ * max|gamma (y - mean) invstd + beta| over the batch: |gamma| sqrt(count - 1) sigma invstd + |beta| (Samuelson's inequality).
+ * It is the fp16x3 operand scale of that activation (see "fp16x3 operand scales" below). */
 int facl_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
                      float eps, float momentum, float* running_mean, float* running_var, float* bnc,
-                     void* stream);
+                     uint32_t* aamax, void* stream);
 int facl_bn_eval_consts(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* bnc, void* stream);
 
@@ -100,10 +103,13 @@ int facl_bn_eval_consts(int C, const float* gamma, const float* beta, const floa
 int facl_sa_x_moments(const float* x, int64_t P, int D, double* mom, void* ws, void* stream);
 int facl_bn1_sums_from_moments(const double* mom, double count, int D, const float* W1, const float* b1,
                                double* sums, void* stream);
+/* xamax -> a1amax (both or neither; FACL_AMAX_WORDS uint32 each): the bound of max|a1| from max|x| (eval-mode constants give
+ * no bound of their own; in training facl_bn_finalize's aamax of BN1 serves) */
 int facl_sa_l1tab(const float* W1, const float* b1, int D, const float* scale, const float* shift,
-                  float* l1tab, void* stream);
+                  float* l1tab, const uint32_t* xamax, uint32_t* a1amax, void* stream);
+/* a1amax: bits of a bound of max|a1| (FACL_AMAX_WORDS uint32): the fp16x3 scale of the layer-1 activation */
 int facl_sa_fwd2(const float* x, int64_t nunits, int D, const float* l1tab, const float* W2,
-                 const float* b2, float* y2f, double* sums2, void* ws, void* stream);
+                 const float* b2, float* y2f, double* sums2, void* ws, const uint32_t* a1amax, void* stream);
 int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,
                  const float* W3, const float* b3, const float* sgn3, float* ymax, uint8_t* arg,
                  double* sums3, void* ws, void* stream);
@@ -114,13 +120,22 @@ int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const fl
 int facl_sa_fwd3_f16(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
                      const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
                      void* stream);
-/* fp16x3 twin of facl_sa_fwd3 (csrc/common.h: a2 * 2^4 and W3 * 2^8 as two fp16 planes each, three products per
- * multiply-add, fp32 accumulation): fp32-GEMM accuracy at half the MFMA work; same outputs.  The model's default. */
+/* fp16x3 twin of facl_sa_fwd3 (csrc/common.h: a2 and W3 as two fp16 planes each of the operand times a power of two
+ * taken from its own maximum / bound, three products per multiply-add, fp32 accumulation): fp32-GEMM accuracy at half the
+ * MFMA work; same outputs.  The model's default.  a2amax: bits of a bound of max|relu(bn2(y2))| (FACL_AMAX_WORDS uint32). */
 int facl_sa_fwd3_h3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2, const float* W3,
                     const float* b3, const float* sgn3, float* ymax, uint8_t* arg, double* sums3, void* ws,
-                    void* stream);
+                    const uint32_t* a2amax, void* stream);
+/* amax (or NULL): FACL_AMAX_WORDS uint32 (zeroed, or holding the maximum of a tensor that shares the scale) raised to the
+ * bits of max(pooled) */
 int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
-                 float* pooled, void* stream);
+                 float* pooled, uint32_t* amax, void* stream);
+/* ---- fp16x3 operand scales: measured maxima for operands no BatchNorm bounds ----
+ *   facl_absmax          raises the slots of `amax` (FACL_AMAX_WORDS uint32, zeroed by the caller or pre-seeded) to max|x|
+ *   facl_rows_act_amax   the same for max relu(scale[c] y[r][c] + shift[c]) of a (R,C) array (eval-mode layers: running
+ *                        statistics say nothing about the data) */
+int facl_absmax(const float* x, int64_t n, uint32_t* amax, void* stream);
+int facl_rows_act_amax(const float* y, int64_t R, int C, const float* scale, const float* shift, uint32_t* amax, void* stream);
 
 /* ---- set-abstraction point-MLP backward (autograd of net3DV_1) ---------------------------
  * See csrc/sa_bwd.hip for the algebra ("BN-affine folding": the dense part of BN3's backward is
@@ -139,12 +154,13 @@ int facl_sa_bwd0(const float* dpooled, const float* ymax, int64_t rows, const fl
                  double* sums, void* ws, void* stream);
 int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2, const float* G3, const float* h3,
                  const float* W3, const float* coef, const uint8_t* arg, float* dz2f, double* sums,
-                 void* ws, void* stream);
+                 void* ws, const uint32_t* a2amax, void* stream);
 int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc2, const float* coef,
-                   const uint8_t* arg, double* out, void* ws, void* stream);
+                   const uint8_t* arg, double* out, void* ws, const uint32_t* a2amax, void* stream);
+/* a1amax / a2amax: the activation bounds the forward passes were given (facl_sa_fwd2 / facl_sa_fwd3_h3) */
 int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x, int64_t nunits, int D,
                  const float* bw2, const float* W2, const float* l1tab, double* out, void* ws,
-                 void* stream);
+                 const uint32_t* a1amax, void* stream);
 /* fp64 closed-form assembly between those passes (csrc/finalize.hip).  "_g" = after the SyncBN all-reduce,
  * "_l" = this rank's sums (parameter gradients stay local; the data-parallel wrapper averages them).
  *   facl_sa_bwd_consts3  sums0 (dbeta3,dgamma3) -> G3 (64,64), h3 (64) for facl_sa_bwd1
@@ -259,15 +275,19 @@ int facl_gemm_wgrad_f16(const float* dy, const float* a, int64_t M, int N, int K
  *                            previous layer's BatchNorm2d + ReLU, :62-63: the activation is never materialised); sums (N,2)
  *                            as facl_gemm_fwd; sgn / ymax / arg (all or none) as facl_gemm_fwd_segmax (M % 64 == 0)
  *   `half` (planes and forward): 0 = three bf16 planes, six products per multiply-add (bf16x6); 1 = two fp16 planes of the
- *                            operands pre-scaled by 2^8 (weights) / 2^4 (activations), THREE products (fp16x3, csrc/common.h):
- *                            the same fp32-GEMM accuracy (22-bit operands, fp32 accumulation) at half the MFMA work
- *                            (|a| < 4094, |w| < 255: beyond that an fp16 piece overflows and the output is NaN, not a wrong
- *                            number); the planes must have been built with the same `half`
+ *                            operands times a power of two, THREE products (fp16x3, csrc/common.h): the same fp32-GEMM
+ *                            accuracy (22-bit operands, fp32 accumulation) at half the MFMA work.  No operand has a fixed
+ *                            scale: the weights carry one power of two per 32-column tile (max|w| of the tile, taken by
+ *                            facl_gemm_rs_planes and stored behind the planes), the row operand takes its scale from
+ *                            `amax_a` (forward: FACL_AMAX_WORDS uint32 with the bits of a bound of max|f(a)| -- and of
+ *                            max|centers| when centres are given -- from facl_bn_finalize / facl_sa_pool / facl_absmax /
+ *                            facl_rows_act_amax); the planes must have been built with the same `half`
  *   facl_gemm_rs_dgrad       da (M,K) = dy (M,N) W.  half = 1: fp16x3 with dy's scale chosen per launch from `amax` (the
  *                            FACL_AMAX_WORDS buffer of facl_rows_bwd_apply_amax / facl_segmax_bwd_apply_amax): the
  *                            power of two that puts the maximum in [2^13, 2^14); elements down to 2^-16 of the maximum keep
  *                            22 bits, smaller ones lose at most 2^-38 of the maximum
- *   facl_gemm_rs_wgrad       amax non-null: the same arithmetic (dy by its dynamic scale, f(y) by 2^4)
+ *   facl_gemm_rs_wgrad       amax non-null: the same arithmetic (dy by its scale, f(y) by the scale of `amax_b`, the bound the
+ *                            forward GEMM that consumed f(y) was given)
  *   facl_gemm_wgrad_pro      dW (N,K) = dy^T relu(pscale*y + pshift): facl_gemm_wgrad whose `a` operand is recomputed from
  *                            the previous layer's raw output y (M,K) while it is staged (the companion of the forward
  *                            prologue: the activation tensor never exists); `_x3`: the opt-in three-product arithmetic.
@@ -276,18 +296,20 @@ int facl_gemm_wgrad_pro(const float* dy, const float* y, int64_t M, int N, int K
                         const float* pshift, float* dW, float* slices, int nz, void* stream);
 int facl_gemm_wgrad_pro_x3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
                            const float* pshift, float* dW, float* slices, int nz, void* stream);
-/* the same weight gradient in fp16x3 (see `half` above): dy by the dynamic scale read from `amax` (the FACL_AMAX_WORDS buffer of
- * facl_rows_bwd_apply_amax), the activation operand by 2^4; pscale / pshift null: `y` IS the activation.  FACL_E_CONFIG when
- * the shape is not served by the 128x128-tile kernel (callers use the bf16x6 entries). */
+/* the same weight gradient in fp16x3 (see `half` above): dy by the scale read from `amax` (the FACL_AMAX_WORDS buffer of
+ * facl_rows_bwd_apply_amax), the activation operand by the one read from `amax_b` (its bound, same format); pscale / pshift
+ * null: `y` IS the activation.  FACL_E_CONFIG when the shape is not served by the 128x128-tile kernel (callers use the
+ * bf16x6 entries). */
 int facl_gemm_wgrad_h3(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,
-                       const float* pshift, const uint32_t* amax, float* dW, float* slices, int nz, void* stream);
+                       const float* pshift, const uint32_t* amax, const uint32_t* amax_b, float* dW, float* slices, int nz,
+                       void* stream);
 /* Weight gradient of the widest layer on the register-streamed kernel (csrc/gemm_rs.hip: k_wgrad_rs): dW (N,K) =
  * dy^T f(y), f = relu(pscale*y + pshift) when pscale is given (else identity).  facl_gemm_rs_wgrad_slices returns the number
  * of row slices the call will use (scratch = that many x N x K floats), or 0 when the shape is not served (N % 512, K % 128,
  * M >= 4096 and at least 8 output blocks): facl_gemm_rs_wgrad then returns FACL_E_CONFIG and callers use facl_gemm_wgrad[_pro]. */
 int facl_gemm_rs_wgrad_slices(int64_t M, int N, int K);
 int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, int N, int K, const float* pscale, const float* pshift,
-                       const uint32_t* amax, float* dW, float* slices, void* stream);
+                       const uint32_t* amax, const uint32_t* amax_b, float* dW, float* slices, void* stream);
 int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
 int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, int half,
                         void* planes, void* stream);
@@ -296,9 +318,9 @@ int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, cons
                               const int* transposed, const float* const* Wc, const int* ldwc, const int* half,
                               void* const* planes, void* stream);
 int facl_gemm_rs_supported(int64_t M, int K, int N);
-int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, int N, const float* bias, const float* pscale,
-                     const float* pshift, const float* centers, float* y, double* sums, const float* sgn, float* ymax,
-                     int32_t* arg, void* ws, void* stream);
+int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, const uint32_t* amax_a, int N,
+                     const float* bias, const float* pscale, const float* pshift, const float* centers, float* y, double* sums,
+                     const float* sgn, float* ymax, int32_t* arg, void* ws, void* stream);
 int facl_gemm_rs_dgrad(const float* dy, int64_t M, int N, const void* planes, int half, const uint32_t* amax, int K,
                        float* da, void* stream);
 /* facl_gemm_rs_dgrad + facl_rows_bwd_stats(da, y, bnc) in one pass: sums (K,2) = the BatchNorm-backward column sums of the

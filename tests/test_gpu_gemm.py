@@ -214,7 +214,7 @@ def test_gemm_rs_fwd_equals_gemm_fwd_and_fp64(M, K, N, pro, ctr, seg):
     y, sums = _lib.empty(M, N, device=DEV), _lib.empty(N, 2, dtype=torch.float64, device=DEV)
     ymax = _lib.empty(M // 64, N, device=DEV) if seg else None
     arg = _lib.empty(M // 64, N, dtype=torch.int32, device=DEV) if seg else None
-    _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), 0, N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax), p(arg),
+    _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), 0, None, N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax), p(arg),
                                     p(_ws()), _lib.stream()), "rs_fwd")
     # reference 1: fp64
     a64 = a.double()
@@ -305,7 +305,7 @@ def test_gemm_rs_wgrad_vs_fp64_and_staged_kernel(M, N, K, pro):
     pt = torch.randn(K, device=DEV, generator=g) * 0.3 if pro else None
     dW, sl = _lib.empty(N, K, device=DEV), _lib.empty(nz * N * K, device=DEV)
     p = _lib.ptr
-    _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y), M, N, K, p(ps), p(pt), None, p(dW), p(sl), _lib.stream()), "rs_wgrad")
+    _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y), M, N, K, p(ps), p(pt), None, None, p(dW), p(sl), _lib.stream()), "rs_wgrad")
     a = torch.relu(y * ps + pt) if pro else y
     a64 = torch.relu(y.double() * ps.double() + pt.double()) if pro else y.double()
     ref = dy.double().t() @ a64
@@ -314,6 +314,21 @@ def test_gemm_rs_wgrad_vs_fp64_and_staged_kernel(M, N, K, pro):
     _lib.check(lib.facl_gemm_wgrad(p(dy), p(a), M, N, K, K, p(dW2), p(sl2), 8, _lib.stream()), "wgrad")
     assert rel_err(dW.cpu().numpy(), dW2.cpu().numpy()) < 2e-6
     assert lib.facl_gemm_rs_wgrad_slices(49152, 512, 256) == 0          # too few output blocks: left to the staged kernel
+
+
+def _act_amax(lib, a, ps=None, pt=None, cen=None):
+    """The FACL_AMAX_WORDS buffer facl_gemm_rs_fwd (half = 1) takes its row operand's power-of-two scale from: the measured
+    maximum of f(a) (facl_rows_act_amax with a prologue, facl_absmax without) and of the centre coordinates."""
+    from facl_amd import _lib
+    p = _lib.ptr
+    amax = _lib.amax_buffers(1, a.device)[0]
+    if ps is not None:
+        _lib.check(lib.facl_rows_act_amax(p(a), a.shape[0], a.shape[1], p(ps), p(pt), p(amax), _lib.stream()), "rows_act_amax")
+    else:
+        _lib.check(lib.facl_absmax(p(a), a.numel(), p(amax), _lib.stream()), "absmax")
+    if cen is not None:
+        _lib.check(lib.facl_absmax(p(cen), cen.numel(), p(amax), _lib.stream()), "absmax")
+    return amax
 
 
 @pytest.mark.parametrize("M,K,N,pro,ctr,seg", [(4096, 256, 256, False, True, False), (4000, 256, 512, True, False, False),
@@ -338,13 +353,14 @@ def test_gemm_rs_fwd_fp16x3_is_fp32_grade(M, K, N, pro, ctr, seg):
     sgn = torch.randn(N, device=DEV, generator=g) if seg else None
     p = _lib.ptr
     outs = {}
+    amax = _act_amax(lib, a, ps, pt, cen)
     for half in (1, 0):
         planes = _rs_planes(lib, W, False, Wc, half)
         y, sums = _lib.empty(M, N, device=DEV), _lib.empty(N, 2, dtype=torch.float64, device=DEV)
         ymax = _lib.empty(M // 64, N, device=DEV) if seg else None
         arg = _lib.empty(M // 64, N, dtype=torch.int32, device=DEV) if seg else None
-        _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), half, N, p(b), p(ps), p(pt), p(cen), p(y), p(sums), p(sgn), p(ymax),
-                                        p(arg), p(_ws()), _lib.stream()), "rs_fwd")
+        _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), half, p(amax) if half else None, N, p(b), p(ps), p(pt), p(cen), p(y),
+                                        p(sums), p(sgn), p(ymax), p(arg), p(_ws()), _lib.stream()), "rs_fwd")
         outs[half] = (y, sums, ymax, arg)
     a64 = a.double()
     if pro:
@@ -436,8 +452,8 @@ def test_gemm_rs_backward_fp16x3_dynamic_scale(M, N, K, mag):
         errs = {}
         for half in (1, 0):
             dW, sl = _lib.empty(N, K2, device=DEV), _lib.empty(nz * N * K2, device=DEV)
-            _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y2), M, N, K2, p(ps), p(pt), p(amax) if half else None, p(dW), p(sl),
-                                              _lib.stream()), "rs_wgrad")
+            _lib.check(lib.facl_gemm_rs_wgrad(p(dy), p(y2), M, N, K2, p(ps), p(pt), p(amax) if half else None,
+                                              p(_act_amax(lib, y2, ps, pt)) if half else None, p(dW), p(sl), _lib.stream()), "rs_wgrad")
             errs[half] = rel_err(dW.cpu().numpy(), refw.cpu().numpy())
         print(f"wgrad fp16x3 {errs[1]:.2e}   bf16x6 {errs[0]:.2e}")
         assert errs[1] < 3e-6 and errs[1] < 2.0 * errs[0]
@@ -449,8 +465,8 @@ def test_gemm_rs_backward_fp16x3_dynamic_scale(M, N, K, mag):
         refw = dy.double().t() @ a64
         nz = 256 // ((N // 128) * (K3 // 128)) + 1                     # at least one resident round of 128x128 workgroups
         dW, sl = _lib.empty(N, K3, device=DEV), _lib.empty(nz * N * K3, device=DEV)
-        rc = lib.facl_gemm_wgrad_h3(p(dy), p(y3), M, N, K3, K3, p(ps) if pro else None, p(pt) if pro else None, p(amax), p(dW), p(sl),
-                                    nz, _lib.stream())
+        rc = lib.facl_gemm_wgrad_h3(p(dy), p(y3), M, N, K3, K3, p(ps) if pro else None, p(pt) if pro else None, p(amax),
+                                    p(_act_amax(lib, y3, ps if pro else None, pt if pro else None)), p(dW), p(sl), nz, _lib.stream())
         _lib.check(rc, "wgrad_h3")
         e = rel_err(dW.cpu().numpy(), refw.cpu().numpy())
         print(f"wgrad (staged kernel) fp16x3 {e:.2e}  pro={pro}")
@@ -478,10 +494,44 @@ def test_segmax_bwd_apply_amax_publishes_the_exact_maximum():
     assert float(amax.view(torch.float32).max()) == float(dy.abs().max())
 
 
-def test_fp16x3_forward_range_contract_fails_loudly():
-    """fp16x3's range contract (include/facl_hip.h): forward activations below 4094 and weights below 255 in magnitude.
-    Inside it the result is fp32-grade up to the edge; beyond it an fp16 piece overflows and the affected outputs are
-    NaN / inf -- never a finite wrong number -- while half = 0 (bf16x6) has no such limit."""
+@pytest.mark.parametrize("sw,sa", [(2.0 ** -12, 1.0), (2.0 ** 6, 1.0), (1.0, 2.0 ** -9), (1.0, 2.0 ** 7), (2.0 ** 20, 2.0 ** -20),
+                                   (2.0 ** -25, 2.0 ** 30)])
+@pytest.mark.parametrize("pro", [False, True])
+def test_fp16x3_forward_is_scale_equivariant(sw, sa, pro):
+    """fp16x3 has NO range contract (rounds 1-3: activations 2^4, weights 2^8 fixed, i.e. |a| < 4094, |w| < 255 or NaN, and
+    15-18 bits for uniformly tiny tensors): every operand is scaled by the power of two of its own maximum / bound
+    (csrc/common.h).  Scaling W or a by powers of two from 2^-25 to 2^30 scales the exact result by the same factor: the GEMM
+    must stay within 2e-6 of the fp64 product at every scale (with the BatchNorm + ReLU prologue the scale sits on the
+    prologue constants, as a tiny / huge gamma would put it there)."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    p = _lib.ptr
+    M, K, N = 4096, 256, 512
+    g = torch.Generator(device=DEV).manual_seed(17)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    a[:, ::7] *= 1e-3
+    W = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5 * sw).contiguous()
+    W[::5] *= 2.0 ** -6                                               # column tiles of different magnitude: one scale per 32 columns
+    b = torch.randn(N, device=DEV, generator=g) * (sw * sa)
+    if pro:
+        ps, pt = (torch.rand(K, device=DEV, generator=g) + 0.5) * sa, torch.randn(K, device=DEV, generator=g) * (0.3 * sa)
+    else:
+        a, ps, pt = (a * sa).contiguous(), None, None
+    planes = _rs_planes(lib, W, False, None, 1)
+    y = _lib.empty(M, N, device=DEV)
+    _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), 1, p(_act_amax(lib, a, ps, pt)), N, p(b), p(ps), p(pt), None, p(y), None,
+                                    None, None, None, p(_ws()), _lib.stream()), "rs_fwd")
+    a64 = torch.relu(a.double() * ps.double() + pt.double()) if pro else a.double()
+    ref = a64 @ W.double().t() + b.double()
+    e = rel_err(y.cpu().numpy(), ref.cpu().numpy())
+    print(f"W x {sw:.1e}, a x {sa:.1e}, prologue {pro}: {e:.2e}")
+    assert torch.isfinite(y).all() and e < 2e-6
+
+
+def test_fp16x3_large_weights_and_activations_are_finite_and_correct():
+    """The numbers the old contract excluded: a |w| = 300 weight, a 5000.0 activation (5000 * 2^4 overflowed fp16), and a
+    bound that is 2^10 too generous (Samuelson's inequality at 3 M positions is) -- finite, 2e-6 of fp64.  Poisoned inputs
+    stay loud: a NaN activation gives a NaN output row, nothing else."""
     from facl_amd import _lib
     lib = _lib.load_library()
     p = _lib.ptr
@@ -490,19 +540,58 @@ def test_fp16x3_forward_range_contract_fails_loudly():
     a = torch.randn(M, K, device=DEV, generator=g)
     W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
     b = torch.zeros(N, device=DEV)
-    a[5, 7] = 4000.0                                                   # inside: 4000 * 2^4 < 65504
-    W[3, 9] = 250.0
-    def run(half):
-        planes = _rs_planes(lib, W, False, None, half)
+    a[5, 7] = 5000.0
+    W[3, 9] = 300.0
+
+    def run(amax):
+        planes = _rs_planes(lib, W, False, None, 1)
         y = _lib.empty(M, N, device=DEV)
-        _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), half, N, p(b), None, None, None, p(y), None, None, None, None,
+        _lib.check(lib.facl_gemm_rs_fwd(p(a), M, K, p(planes), 1, p(amax), N, p(b), None, None, None, p(y), None, None, None, None,
                                         p(_ws()), _lib.stream()), "rs_fwd")
         return y
     ref = a.double() @ W.double().t()
-    assert rel_err(run(1).cpu().numpy(), ref.cpu().numpy()) < 2e-6
-    a[5, 7] = 5000.0                                                   # outside: 5000 * 2^4 overflows fp16
-    y1, y0 = run(1), run(0)
+    amax = _act_amax(lib, a)
+    y = run(amax)
+    assert torch.isfinite(y).all() and rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    # a bound 2^10 above the true maximum of ordinary (outlier-free) activations -- what Samuelson's inequality gives at 3 M
+    # positions -- costs nothing measurable: the elements still sit within the 16 octaves that keep 22 bits
+    a[5, 7] = 1.0
     ref = a.double() @ W.double().t()
-    assert not torch.isfinite(y1[5]).all()                             # loud on the affected row ...
-    assert torch.isfinite(y1[:5]).all() and torch.isfinite(y1[6:]).all()   # ... and only there
-    assert rel_err(y0.cpu().numpy(), ref.cpu().numpy()) < 2e-6         # bf16x6: no range limit
+    loose = (_act_amax(lib, a).view(torch.float32) * 1024.0).view(torch.int32).contiguous()
+    y = run(loose)
+    assert torch.isfinite(y).all() and rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert lib.facl_gemm_rs_fwd(p(a), M, K, p(_rs_planes(lib, W, False, None, 1)), 1, None, N, p(b), None, None, None, p(y), None, None,
+                                None, None, p(_ws()), _lib.stream()) == -2       # FACL_E_NULL: fp16x3 needs the operand's maximum
+    a[9, 3] = float("nan")
+    y = run(_act_amax(lib, a))
+    assert not torch.isfinite(y[9]).any() and torch.isfinite(y[:9]).all() and torch.isfinite(y[10:]).all()
+
+
+def test_eval_mode_net3dv3_propagates_a_nan_like_torch():
+    """relu / max-pool of the row-streamed path must not swallow a NaN (fmaxf(NaN, 0) = 0; `v > best` skips NaN) --
+    torch.relu and MaxPool2d propagate it.  One poisoned centroid row through net3DV_3 in eval mode: that cloud's x_pre is
+    non-finite, every other cloud's is finite and unchanged."""
+    from types import SimpleNamespace
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from oracle.weights import formula_state_dict
+    opt = SimpleNamespace(temperal_num=3, knn_K=64, ball_radius=0.16, ball_radius2=0.25, sample_num_level1=64, sample_num_level2=64,
+                          INPUT_FEATURE_NUM=4, Num_Class=512, batchSize=8, pooling="concatenation", SAMPLE_NUM=512)
+    net = PointNet_Plus(opt, gost=4)
+    net.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(4).items()})
+    net = net.to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M, S = 32, 64
+    pooled = torch.rand(M * S, 256, device=DEV, generator=g)
+    centers = torch.rand(M * S, 3, device=DEV, generator=g) - 0.5
+    from facl_amd import tail
+    assert tail.net3dv3_supported(M * S, (256, 256, 512, 1024), S, "f32")
+    with torch.no_grad():
+        clean = tail.net3dv3(pooled, centers, net.net3DV_3, False, S)
+        pooled[5 * S + 17, 100] = float("nan")
+        bad = tail.net3dv3(pooled, centers, net.net3DV_3, False, S)
+    assert torch.isfinite(clean).all()
+    assert not torch.isfinite(bad[5]).any()
+    keep = [i for i in range(M) if i != 5]
+    assert torch.isfinite(bad[keep]).all()
+
+

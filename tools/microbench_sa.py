@@ -52,7 +52,9 @@ def main():
     W1, b1 = R(64, D) * 0.3, R(64) * 0.1
     W2, b2, W3, b3 = R(64, 64) * 0.1, R(64) * 0.1, R(256, 64) * 0.1, R(256) * 0.1
     l1tab = torch.empty(64, 8, device=dev)
-    _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(b1), D, None, None, _lib.ptr(l1tab), _lib.stream()), "l1tab")
+    _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(b1), D, None, None, _lib.ptr(l1tab), None, None, _lib.stream()), "l1tab")
+    # fp16x3 activation bounds (csrc/common.h) for these random inputs: every slot of the two buffers holds the bits of 8.0
+    am = torch.full((2, _lib.AMAX_WORDS), 8.0, device=dev).view(torch.int32)
     sgn = torch.ones(256, device=dev)
     ymax, arg = torch.empty(nunits, 256, device=dev), torch.randint(0, 64, (nunits, 256), dtype=torch.uint8, device=dev)
     coef = R(nunits, 256)
@@ -68,13 +70,13 @@ def main():
     F = 2.0 * 64 * 64 * P          # flops of one 64x64 layer over all positions
     def make(lib):
       return {
-        "fwd2": (lambda: lib.facl_sa_fwd2(p(x), nunits, D, p(l1tab), p(W2), p(b2), p(dz2f), p(s64), p(ws), st), F),
+        "fwd2": (lambda: lib.facl_sa_fwd2(p(x), nunits, D, p(l1tab), p(W2), p(b2), p(dz2f), p(s64), p(ws), p(am[0]), st), F),
         "fwd3": (lambda: lib.facl_sa_fwd3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), st), 4 * F),
-        "fwd3h": (lambda: lib.facl_sa_fwd3_h3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), st), 4 * F),
+        "fwd3h": (lambda: lib.facl_sa_fwd3_h3(p(y2f), nunits, p(bnc2[2]), p(bnc2[3]), p(W3), p(b3), p(sgn), p(ymax), p(arg), p(s256), p(ws), p(am[1]), st), 4 * F),
         "bwd0": (lambda: lib.facl_sa_bwd0(p(coef), p(ymax), nunits, p(bnc3), p(coef), p(s256), p(ws), st), 0),
-        "bwd1": (lambda: lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg), p(dz2f), p(s64), p(ws), st), F),
-        "bwd_w3": (lambda: lib.facl_sa_bwd_w3(p(y2f), nunits, p(bnc2), p(coef), p(arg), p(o3), p(ws), st), 0.75 * F),
-        "bwd2": (lambda: lib.facl_sa_bwd2(p(dz2f), p(y2f), p(x), nunits, D, p(bw2), p(W2), p(l1tab), p(o2), p(ws), st), 2.5 * F),
+        "bwd1": (lambda: lib.facl_sa_bwd1(p(y2f), nunits, p(bnc2), p(G3), p(h3), p(W3), p(coef), p(arg), p(dz2f), p(s64), p(ws), p(am[1]), st), F),
+        "bwd_w3": (lambda: lib.facl_sa_bwd_w3(p(y2f), nunits, p(bnc2), p(coef), p(arg), p(o3), p(ws), p(am[1]), st), 0.75 * F),
+        "bwd2": (lambda: lib.facl_sa_bwd2(p(dz2f), p(y2f), p(x), nunits, D, p(bw2), p(W2), p(l1tab), p(o2), p(ws), p(am[0]), st), 2.5 * F),
       }
     kernels = make(lib)
     kernels_b = make(lib_b) if lib_b is not None else None

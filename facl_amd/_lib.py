@@ -35,7 +35,7 @@ SIGNATURES = {
     "facl_adam_prep": [c_p, c_p, c_f, c_f, c_p, c_p],
     "facl_adam_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p],
     "facl_ws_bytes": [],
-    "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p],
+    "facl_bn_finalize": [c_p, c_i, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_absmax": [c_p, c_l, c_p, c_p],
     "facl_rows_act_amax": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],
@@ -71,7 +71,7 @@ SIGNATURES = {
     "facl_gemm_rs_wgrad": [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_planes_bytes": [c_i, c_i, c_i],
     "facl_gemm_rs_planes": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
-    "facl_gemm_rs_planes_multi": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_rs_planes_multi": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p],
     "facl_gemm_rs_supported": [c_l, c_i, c_i],
     "facl_gemm_rs_fwd": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_rs_dgrad": [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p],
@@ -139,11 +139,14 @@ def check(rc, what):
 AMAX_WORDS = 2048          # include/facl_hip.h: FACL_AMAX_WORDS
 
 
-def amax_buffers(n, device):
-    """(n, AMAX_WORDS) int32 zeros: n operand-maximum buffers of the fp16x3 GEMMs (csrc/common.h).  Producers either store a
-    bound into every slot (facl_bn_finalize) or RAISE slots with atomics (facl_sa_pool, facl_absmax, the BatchNorm-backward
-    row kernels), which is why they start from zero."""
-    return torch.zeros((n, AMAX_WORDS), dtype=torch.int32, device=device)
+def amax_buffers(n, device, zero=True):
+    """(n, AMAX_WORDS) int32: n operand-maximum buffers of the fp16x3 GEMMs (csrc/common.h).  Producers either STORE a bound
+    into every slot (facl_bn_finalize) or RAISE slots with atomics (facl_sa_pool, facl_absmax, the BatchNorm-backward row
+    kernels): the latter need zeros to start from -- `zero=False` when every row is stored or zeroed by a kernel of the step
+    itself (facl_bn_finalize's `zamax`), which spares the fill launch."""
+    if zero:
+        return torch.zeros((n, AMAX_WORDS), dtype=torch.int32, device=device)
+    return empty((n, AMAX_WORDS), dtype=torch.int32, device=device)
 
 
 def ptr(t):

@@ -44,9 +44,11 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const double* __restrict__
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                       float momentum, float* __restrict__ running_mean,
                                                       float* __restrict__ running_var, float* __restrict__ bnc,
-                                                      unsigned* __restrict__ aamax) {
+                                                      unsigned* __restrict__ aamax, unsigned* __restrict__ zamax) {
     __shared__ float red[16];
     float bound = 0.f;
+    if (zamax)
+        for (int i = threadIdx.x; i < FACL_AMAX_WORDS; i += blockDim.x) zamax[i] = 0u;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const double mean = sums[2 * c] / count;
         double var = sums[2 * c + 1] / count - mean * mean;
@@ -204,12 +206,12 @@ extern "C" int64_t facl_ws_bytes(void) { return (int64_t)FACL_WS_ROWS * 4608 * s
 
 extern "C" int facl_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* bnc,
-                                uint32_t* aamax, void* stream) {
+                                uint32_t* aamax, uint32_t* zamax, void* stream) {
     if (!sums || !gamma || !beta || !bnc) return FACL_E_NULL;
     if (C < 1 || count < 1) return FACL_E_SHAPE;
     const int threads = C >= 1024 ? 1024 : (C + 63) / 64 * 64;
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(threads), 0, (hipStream_t)stream, sums, C, count, gamma,
-                       beta, eps, momentum, running_mean, running_var, bnc, aamax);
+                       beta, eps, momentum, running_mean, running_var, bnc, aamax, zamax);
     return facl_launch_status();
 }
 

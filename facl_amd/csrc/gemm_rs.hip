@@ -70,31 +70,40 @@ struct RsArgs {
 // can undo it per tile): 2^(13 - floor(log2 max|w|)) over the tile's 32 columns x the whole contraction (centre columns
 // included), stored as its biased exponent in `hdr[tile]` behind the planes.  One workgroup per (matrix, column tile): a
 // first pass over the tile takes the maximum, a second one splits (the tile is 4-128 KiB: L2 hits).
+constexpr int RS_PL_ITEMS = 16;                   // items (8 weights each) a thread holds: at most 64 k-steps (contraction <= 1024)
 __device__ __forceinline__ void rs_planes_tile(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
                                                const float* __restrict__ xc, int ldxc, uint4* __restrict__ out, int half,
                                                int* __restrict__ hdr, int ot) {
     __shared__ float red[16];
     const int NT = NO >> 5, nks = NC >> 4, nitems = (nks + (xc ? 1 : 0)) * 64;
-    auto load8 = [&](int item, float (&v)[8]) {
+    // ONE pass over the tile: every thread keeps its items in registers (all loads in flight at once; the first version read
+    // the tile twice, one dependent item at a time: 21 us per step instead of 7), takes the maximum, then splits from registers
+    float v[RS_PL_ITEMS][8];
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < RS_PL_ITEMS; ++t) {
+        const int item = threadIdx.x + 256 * t;
         const int ln = item & 63, ks = item >> 6;
         const int o = 32 * ot + (ln & 31), hh = ln >> 5;
-        if (ks < nks) {
+        if (item < nitems) {
+            if (ks < nks) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = W[(long long)o * so + (long long)(16 * ks + 8 * hh + j) * sc];
+                for (int j = 0; j < 8; ++j) v[t][j] = W[(long long)o * so + (long long)(16 * ks + 8 * hh + j) * sc];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[t][j] = (hh == 0 && j < 3) ? xc[(long long)o * ldxc + j] : 0.f;
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (hh == 0 && j < 3) ? xc[(long long)o * ldxc + j] : 0.f;
+            for (int j = 0; j < 8; ++j) v[t][j] = 0.f;
         }
-    };
+    }
     float sw = 1.f;
     if (half) {
-        float m = 0.f;
-        for (int item = threadIdx.x; item < nitems; item += 256) {
-            float v[8];
-            load8(item, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
-        }
+        for (int t = 0; t < RS_PL_ITEMS; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[t][j]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -104,26 +113,38 @@ __device__ __forceinline__ void rs_planes_tile(const float* __restrict__ W, long
         if (threadIdx.x == 0) hdr[ot] = se;
         sw = pow2_biased(se);
     }
-    for (int item = threadIdx.x; item < nitems; item += 256) {
+#pragma unroll
+    for (int t = 0; t < RS_PL_ITEMS; ++t) {
+        const int item = threadIdx.x + 256 * t;
+        if (item >= nitems) break;
         const int ln = item & 63, ks = item >> 6;
-        float v[8];
-        load8(item, v);
         unsigned hi[4], mi[4], lo[4];
         if (half) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j] * sw, v[2 * j + 1] * sw, hi[j], lo[j]);
+            for (int j = 0; j < 4; ++j) split_pair_h(v[t][2 * j] * sw, v[t][2 * j + 1] * sw, hi[j], lo[j]);
             uint4* d = out + ((long long)(ks * NT + ot) * 2) * 64 + ln;
             d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             d[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             continue;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
+        for (int j = 0; j < 4; ++j) split_pair(v[t][2 * j], v[t][2 * j + 1], hi[j], mi[j], lo[j]);
         uint4* d = out + ((long long)(ks * NT + ot) * 3) * 64 + ln;
         d[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         d[64] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
         d[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
+}
+
+// max|x| of a small array RAISED into the slots of an amax buffer by the extra workgroups of the planes launch (the centroid
+// coordinates share the scale of the first layer's row operand: no launch of their own)
+__device__ __forceinline__ void rs_absmax_block(const float* __restrict__ x, long long n, unsigned* __restrict__ amax, int b, int nb) {
+    float m = 0.f;
+    for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += (long long)nb * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(amax + ((b * 4 + (threadIdx.x >> 6)) & (FACL_AMAX_SLOTS - 1)) * FACL_AMAX_STRIDE, __float_as_uint(m));
 }
 
 __global__ __launch_bounds__(256) void k_rs_planes(const float* __restrict__ W, long long so, long long sc, int NO, int NC,
@@ -140,8 +161,13 @@ struct RsPlaneJobs {
     const float* W[RS_MAXJOBS]; long long so[RS_MAXJOBS]; long long sc[RS_MAXJOBS]; int NO[RS_MAXJOBS]; int NC[RS_MAXJOBS];
     const float* xc[RS_MAXJOBS]; int ldxc[RS_MAXJOBS]; uint4* out[RS_MAXJOBS]; int* hdr[RS_MAXJOBS]; int first[RS_MAXJOBS + 1];
     int half[RS_MAXJOBS];
+    const float* ax; long long an; unsigned* aamax; int anb;      // optional absmax job: the last `anb` workgroups
 };
 __global__ __launch_bounds__(256) void k_rs_planes_multi(RsPlaneJobs jb) {
+    if ((int)blockIdx.x >= jb.first[jb.n]) {
+        rs_absmax_block(jb.ax, jb.an, jb.aamax, (int)blockIdx.x - jb.first[jb.n], jb.anb);
+        return;
+    }
     int j = 0;
 #pragma unroll
     for (int t = 1; t < RS_MAXJOBS; ++t) j += (t < jb.n && (int)blockIdx.x >= jb.first[t]) ? 1 : 0;
@@ -561,7 +587,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
     auto store_b = [&](int s, const float (&r)[8]) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = PRO ? relu_nan(fmaf(ps, r[e], pt)) : r[e];
+        for (int e = 0; e < 8; ++e) v[e] = PRO ? fmaxf(fmaf(ps, r[e], pt), 0.f) : r[e];   // (backward = training: a NaN is loud through the layer's statistics)
         unsigned hi[4], mi[4], lo[4];
         uint4* d = &bring[s & 1][((ks_b * 4 + kt_b) * NPL) * 64 + lb];
         if (H3) {
@@ -763,7 +789,7 @@ extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int tr
     if (!W || !planes) return FACL_E_NULL;
     if (N < 1 || K < 1 || ldw < K) return FACL_E_SHAPE;
     const int NO = transposed ? K : N, NC = transposed ? N : K;
-    if ((NO & 31) || (NC & 15) || (transposed && Wc)) return FACL_E_SHAPE;
+    if ((NO & 31) || (NC & 15) || (transposed && Wc) || NC / 16 + (Wc ? 1 : 0) > RS_PL_ITEMS * 4) return FACL_E_SHAPE;
     const long long so = transposed ? 1 : ldw, sc = transposed ? ldw : 1;
     int* hdr = (int*)((char*)planes + rs_planes_only_bytes(NO, NC, Wc ? 1 : 0));
     hipLaunchKernelGGL(k_rs_planes, dim3(NO / 32), dim3(256), 0, (hipStream_t)stream, W, so, sc, NO, NC, Wc, ldwc, (uint4*)planes,
@@ -771,12 +797,16 @@ extern "C" int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int tr
     return facl_launch_status();
 }
 
-// n <= 8 matrices in ONE launch; arrays of the per-matrix arguments of facl_gemm_rs_planes
+// n <= 8 matrices in ONE launch; arrays of the per-matrix arguments of facl_gemm_rs_planes.  absmax_x / absmax_n / absmax_amax
+// (all or none): the same launch also raises the slots of `absmax_amax` (FACL_AMAX_WORDS uint32) to max|absmax_x[0 .. n)| --
+// the centroid coordinates, whose k-step shares the fp16x3 scale of the first layer's row operand.
 extern "C" int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, const int* N, const int* K,
                                          const int* transposed, const float* const* Wc, const int* ldwc, const int* half,
-                                         void* const* planes, void* stream) {
+                                         void* const* planes, const float* absmax_x, int64_t absmax_n, uint32_t* absmax_amax,
+                                         void* stream) {
     if (!W || !ldw || !N || !K || !transposed || !Wc || !ldwc || !half || !planes) return FACL_E_NULL;
-    if (n < 1 || n > RS_MAXJOBS) return FACL_E_SHAPE;
+    if ((absmax_x == nullptr) != (absmax_amax == nullptr)) return FACL_E_NULL;
+    if (n < 1 || n > RS_MAXJOBS || (absmax_x && absmax_n < 1)) return FACL_E_SHAPE;
     RsPlaneJobs jb;
     jb.n = n;
     jb.first[0] = 0;
@@ -785,14 +815,16 @@ extern "C" int facl_gemm_rs_planes_multi(int n, const float* const* W, const int
         if (!W[j] || !planes[j]) return FACL_E_NULL;
         if (N[j] < 1 || K[j] < 1 || ldw[j] < K[j]) return FACL_E_SHAPE;
         const int NO = transposed[j] ? K[j] : N[j], NC = transposed[j] ? N[j] : K[j];
-        if ((NO & 31) || (NC & 15) || (transposed[j] && Wc[j])) return FACL_E_SHAPE;
+        if ((NO & 31) || (NC & 15) || (transposed[j] && Wc[j]) || NC / 16 + (Wc[j] ? 1 : 0) > RS_PL_ITEMS * 4) return FACL_E_SHAPE;
         jb.W[j] = W[j]; jb.so[j] = transposed[j] ? 1 : ldw[j]; jb.sc[j] = transposed[j] ? ldw[j] : 1;
         jb.NO[j] = NO; jb.NC[j] = NC; jb.xc[j] = Wc[j]; jb.ldxc[j] = ldwc[j]; jb.out[j] = (uint4*)planes[j];
         jb.hdr[j] = (int*)((char*)planes[j] + rs_planes_only_bytes(NO, NC, Wc[j] ? 1 : 0));
         jb.half[j] = half[j] ? 1 : 0;
         jb.first[j + 1] = jb.first[j] + NO / 32;
     }
-    hipLaunchKernelGGL(k_rs_planes_multi, dim3(jb.first[n]), dim3(256), 0, (hipStream_t)stream, jb);
+    jb.ax = absmax_x; jb.an = absmax_n; jb.aamax = absmax_amax;
+    jb.anb = absmax_x ? (int)((absmax_n + 4095) / 4096 < 16 ? (absmax_n + 4095) / 4096 : 16) : 0;
+    hipLaunchKernelGGL(k_rs_planes_multi, dim3(jb.first[n] + jb.anb), dim3(256), 0, (hipStream_t)stream, jb);
     return facl_launch_status();
 }
 

@@ -536,16 +536,42 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
     float* b3s = reinterpret_cast<float*>(sh2s + 16);   // 256
     // per-wave fp64 (sum, sumsq) of y3 per channel: [ct3][q] (the two lane halves are merged before the update)
     double2* stat = reinterpret_cast<double2*>(b3s + 256) + (threadIdx.x >> 6) * 256;
-    // fp16x3 operand scales (common.h): W3 by the power of two of its own maximum (taken here; the statistics area is idle),
-    // a2 by the one of its bound
+    // fp16x3 operand scales (common.h): W3 by the power of two of its own maximum -- every thread first loads the 32 weights
+    // it is going to split (one pass over W3, all loads in flight), the workgroup takes the maximum, then the fragments are
+    // split from registers --, a2 by the one of its bound
+    float4 wv[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + 512 * it;
+        const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
+        const float* wrow = W3 + (32 * ct3 + (ln & 31)) * 64 + 16 * kk + 4 * (ln >> 5);
+        wv[it][0] = *reinterpret_cast<const float4*>(wrow);
+        wv[it][1] = *reinterpret_cast<const float4*>(wrow + 8);
+    }
     int seW = 127, seA = 127;
-    if (NP == 4) { seW = wg_h3_se(W3, 256 * 64, b3s); seA = h3_se_of(a2amax); }      // LDS scratch: b3s (filled further down)
+    if (NP == 4) {
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(wv[it][e].x), fabsf(wv[it][e].y))), fmaxf(fabsf(wv[it][e].z), fabsf(wv[it][e].w)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) b3s[threadIdx.x >> 6] = m;          // LDS scratch: b3s is filled further down
+        __syncthreads();
+        m = fmaxf(fmaxf(fmaxf(b3s[0], b3s[1]), fmaxf(b3s[2], b3s[3])), fmaxf(fmaxf(b3s[4], b3s[5]), fmaxf(b3s[6], b3s[7])));
+        __syncthreads();
+        seW = __builtin_amdgcn_readfirstlane(h3_se(__float_as_uint(m)));
+        seA = h3_se_of(a2amax);
+    }
     const float sW3 = pow2_biased(seW), sA2 = pow2_biased(seA), UNS = h3_unscale(seA, seW);
-    for (int i = threadIdx.x; i < 2048; i += 512) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + 512 * it;
         const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
         const int c3 = 32 * ct3 + (ln & 31);
-        const float* wrow = W3 + c3 * 64 + 16 * kk + 4 * (ln >> 5);
-        float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 8);
+        float4 w0 = wv[it][0], w1 = wv[it][1];
         const float s = sgn_of(sgn3[c3]);
         unsigned hi[4], mi[4], lo[4];
         if (NP == 4) {                                      // fp16x3: two fp16 planes of w * 2^8 (plane slots 0 and 1)

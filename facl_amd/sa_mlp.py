@@ -32,14 +32,14 @@ class _Workspace:
         return cls._ws[key]
 
 
-def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, aamax=None):
+def _bn_finalize(sums, C, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, aamax=None, zamax=None):
     """`aamax` (one row of _lib.amax_buffers): receives the bound of the layer's activation, the fp16x3 scale of the GEMM that
     consumes it (|gamma| sqrt(count - 1) sigma invstd + |beta|: csrc/finalize.hip)."""
     lib = _lib.load_library()
     bnc = _lib.empty((5, C), dtype=torch.float32, device=sums.device)
     _lib.check(lib.facl_bn_finalize(_lib.ptr(sums), C, float(count), _lib.ptr(gamma), _lib.ptr(beta), BN_EPS,
                                     momentum, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(bnc),
-                                    _lib.ptr(aamax), _lib.stream()), "facl_bn_finalize")
+                                    _lib.ptr(aamax), _lib.ptr(zamax), _lib.stream()), "facl_bn_finalize")
     return bnc
 
 
@@ -125,7 +125,9 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     W3 = p["W3"].reshape(256, 64)
     ctx = {}
     # fp16x3 operand maxima (csrc/common.h): [0] max|x| (eval), [1] bound of a1, [2] bound of a2, [3] max(pooled)
-    amax = _lib.amax_buffers(4, dev)
+    # training: [1], [2] are stored by facl_bn_finalize and [3] is zeroed by BN3's finalize call right before facl_sa_pool
+    # raises it -- no fill launch; eval measures with atomics and starts from zeros
+    amax = _lib.amax_buffers(4, dev, zero=not training)
     if training:
         mom = _lib.empty(D + D * D, **f64)
         _lib.check(lib.facl_sa_x_moments(_lib.ptr(x_rows), P, D, _lib.ptr(mom), _lib.ptr(ws), st), "facl_sa_x_moments")
@@ -190,7 +192,7 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         if reduce_fn is not None:
             reduce_fn(sums3)
         rm, rv = (p["rm3"], p["rv3"]) if direct else (None, None)
-        bnc3 = _bn_finalize(sums3, 256, count, p["g3"], p["be3"], rm, rv)
+        bnc3 = _bn_finalize(sums3, 256, count, p["g3"], p["be3"], rm, rv, zamax=amax[3])
         if update_running and not direct:
             _running_update(bnc3, p["rm3"], p["rv3"], n_true)
     else:

@@ -505,9 +505,10 @@ def rs_planes(W, transposed, centers_cols=None, half=False):
     return planes
 
 
-def rs_planes_multi(jobs):
+def rs_planes_multi(jobs, absmax=None):
     """`jobs`: list of (W view, transposed, centre-column view or None[, half]) -> list of plane buffers, ONE launch.
-    half = True: fp16x3 planes (forward arithmetic of csrc/common.h), else bf16x6 planes."""
+    half = True: fp16x3 planes (forward arithmetic of csrc/common.h), else bf16x6 planes.
+    `absmax` = (tensor, amax row): the same launch raises the amax row to max|tensor| (the centroid coordinates)."""
     jobs = [(j + (False,))[:4] for j in jobs]
     import ctypes
     lib = _lib.load_library()
@@ -523,7 +524,8 @@ def rs_planes_multi(jobs):
         ip(*[j[0].shape[1] for j in jobs]), ip(*[1 if j[1] else 0 for j in jobs]),
         vp(*[None if j[2] is None else j[2].data_ptr() for j in jobs]),
         ip(*[0 if j[2] is None else j[2].stride(0) for j in jobs]), ip(*[1 if j[3] else 0 for j in jobs]),
-        vp(*[o.data_ptr() for o in outs]), _lib.stream()),
+        vp(*[o.data_ptr() for o in outs]), None if absmax is None else _lib.ptr(absmax[0]),
+        0 if absmax is None else absmax[0].numel(), None if absmax is None else _lib.ptr(absmax[1]), _lib.stream()),
         "facl_gemm_rs_planes_multi")
     return outs
 
@@ -658,18 +660,18 @@ class _Net3DV3(torch.autograd.Function):
         want_bwd = training and backward_precision(ctx.prec) == "f32"
         if want_bwd:
             jobs += [(W3, True, None, BWD_H3), (W2, True, None, BWD_H3), (W1[:, 3:], True, None, BWD_H3)]
-        pl = rs_planes_multi(jobs)
-        ctx.bwd_planes = pl[3:] if want_bwd else None
-        ctx.bwd_h3 = want_bwd and BWD_H3
         # fp16x3 operand maxima of the three row operands (csrc/common.h): [0] max(pooled, |centres|) -- the pooled features
-        # bring their exact maximum from facl_sa_pool when the caller hands it over --, [1] / [2] the bounds of a1 / a2
-        amax = _lib.amax_buffers(3, pooled.device)
+        # bring their exact maximum from facl_sa_pool when the caller hands it over; the centres' joins it inside the planes
+        # launch --, [1] / [2] the bounds of a1 / a2 (training: stored by facl_bn_finalize, no fill needed; eval: measured)
+        amax = _lib.amax_buffers(3, pooled.device, zero=(not training) or pooled_amax is None)
         if pooled_amax is not None:
             a0 = pooled_amax
         else:
             a0 = amax[0]
             _lib.check(lib.facl_absmax(_lib.ptr(pooled), pooled.numel(), _lib.ptr(a0), _lib.stream()), "facl_absmax")
-        _lib.check(lib.facl_absmax(_lib.ptr(centers), centers.numel(), _lib.ptr(a0), _lib.stream()), "facl_absmax")
+        pl = rs_planes_multi(jobs, absmax=(centers, a0))
+        ctx.bwd_planes = pl[3:] if want_bwd else None
+        ctx.bwd_h3 = want_bwd and BWD_H3
         y1, sums1, _, _ = _rs_fwd(pooled, pl[0], W1.shape[0], b1, None, centers, training, None, ws, h3, a0)
         bnc1, count = _forward_bn_consts(y1, bns[0], training, reduce_fn, ws, sums1, aamax=amax[1])
         y2, sums2, _, _ = _rs_fwd(y1, pl[1], W2.shape[0], b2, bnc1, None, training, None, ws, h3, amax[1])

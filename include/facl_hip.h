@@ -81,9 +81,10 @@ int64_t facl_ws_bytes(void);   /* size of the scratch buffer `ws` the reducing c
 /* aamax (or NULL): FACL_AMAX_WORDS uint32 that receive (in every slot) the bits of a rigorous BOUND of the layer's activation
  * max|gamma (y - mean) invstd + beta| over the batch: |gamma| sqrt(count - 1) sigma invstd + |beta| (Samuelson's inequality).
  * It is the fp16x3 operand scale of that activation (see "fp16x3 operand scales" below). */
+/* zamax (or NULL): another FACL_AMAX_WORDS buffer that the call ZEROES (the next kernel raises it with atomics: spares a fill launch) */
 int facl_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
                      float eps, float momentum, float* running_mean, float* running_var, float* bnc,
-                     uint32_t* aamax, void* stream);
+                     uint32_t* aamax, uint32_t* zamax, void* stream);
 int facl_bn_eval_consts(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* bnc, void* stream);
 
@@ -314,9 +315,12 @@ int64_t facl_gemm_rs_planes_bytes(int N, int K, int with_centers);
 int facl_gemm_rs_planes(const float* W, int ldw, int N, int K, int transposed, const float* Wc, int ldwc, int half,
                         void* planes, void* stream);
 /* n <= 8 matrices in one launch: arrays (length n) of the per-matrix arguments of facl_gemm_rs_planes */
+/* absmax_x / absmax_n / absmax_amax (all or none): the launch also raises `absmax_amax` (FACL_AMAX_WORDS uint32) to
+ * max|absmax_x[0 .. absmax_n)| -- the centroid coordinates share the fp16x3 scale of the first layer's row operand */
 int facl_gemm_rs_planes_multi(int n, const float* const* W, const int* ldw, const int* N, const int* K,
                               const int* transposed, const float* const* Wc, const int* ldwc, const int* half,
-                              void* const* planes, void* stream);
+                              void* const* planes, const float* absmax_x, int64_t absmax_n, uint32_t* absmax_amax,
+                              void* stream);
 int facl_gemm_rs_supported(int64_t M, int K, int N);
 int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* planes, int half, const uint32_t* amax_a, int N,
                      const float* bias, const float* pscale, const float* pshift, const float* centers, float* y, double* sums,

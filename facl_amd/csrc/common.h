@@ -66,6 +66,8 @@ __device__ __forceinline__ constexpr int rowmap(int r, int h) { return (r & 3) +
 
 // partial-sum workspace: every wave (or block) of a reducing kernel writes one row of doubles
 #define FACL_WS_ROWS 4096
+// the last bytes of the workspace: ticket counters of the single-launch partial-row reduction (finalize.hip), zero between launches
+#define FACL_WS_TICKET_BYTES 4096
 
 // ---- split-bf16 ("bf16x6") helpers ---------------------------------------------------------------------------
 // gfx950 runs the fp32-input MFMA at 1/16 of the bf16 rate.  An fp32 value is split EXACTLY into three bf16 pieces

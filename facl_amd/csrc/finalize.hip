@@ -3,6 +3,9 @@
 // BN semantics: cn3d_model_conbag.py:46,50,54,64,68,72,84 (nn.BatchNorm2d/1d defaults: eps 1e-5,
 // momentum 0.1, biased variance to normalise, unbiased for the running buffer).
 #include "common.h"
+#include <stdlib.h>
+
+extern "C" int64_t facl_ws_bytes(void);
 
 namespace {
 
@@ -179,30 +182,94 @@ __global__ void k_l1tab(const float* __restrict__ W1, const float* __restrict__ 
 
 }  // namespace
 
-// The partials occupy part[0 : rows*V] of the caller's workspace (facl_ws_bytes); the second level's scratch rows
-// go right behind them when they fit, else the reduction stays single-level.
+// part[rows][V] -> out[V] in ONE launch (round 4 experiment, opt-in: FACL_REDUCE_1L=1; see facl_reduce_rows for the measurement).  Grid =
+// (column blocks, row slices): every workgroup sums its slice of rows into scratch[slice][V] exactly as k_reduce_rows does, then
+// takes a ticket of its column block; the workgroup that draws the LAST ticket adds the slices in slice order (fixed order, no
+// floating-point atomics: the result is bit-identical to the two-level form) and hands the ticket counter back at zero, so the
+// launch can be replayed from a captured graph.  Tickets: the last FACL_WS_TICKET_BYTES of the workspace, zero before first use
+// (the caller's duty, once) and zero again after every launch.
+__global__ __launch_bounds__(1024) void k_reduce_rows_t(const double* __restrict__ part, int rows, int V, int rows_per_block,
+                                                        double* __restrict__ scratch, double* __restrict__ out,
+                                                        unsigned* __restrict__ tickets) {
+    __shared__ double red[16][64];
+    __shared__ int is_last;
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int v = blockIdx.x * 64 + col;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    double s0 = 0, s1 = 0;
+    if (v < V) {
+        int r = r0 + rg;
+        for (; r + 16 < r1; r += 32) {
+            s0 += part[(size_t)r * V + v];
+            s1 += part[(size_t)(r + 16) * V + v];
+        }
+        if (r < r1) s0 += part[(size_t)r * V + v];
+    }
+    red[rg][col] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && v < V) {
+        double t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][col];
+        scratch[(size_t)blockIdx.y * V + v] = t;
+        __threadfence();                                  // the slice row is visible device-wide before the ticket is drawn
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int nb = gridDim.y;
+    double t = 0;
+    if (v < V)
+        for (int b = rg; b < nb; b += 16) t += scratch[(size_t)b * V + v];
+    red[rg][col] = t;
+    __syncthreads();
+    if (rg == 0 && v < V) {
+        double a = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[i][col];
+        out[v] = a;
+    }
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
+}
+
+// The partials occupy part[0 : rows*V] of the caller's workspace (facl_ws_bytes); the slice rows go right behind them when
+// they fit, else the reduction stays single-level.  `part` IS the workspace base in every caller (its tail holds the tickets).
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st) {
     const int cb = (V + 63) / 64;
     int nb = 1;
     if (rows >= 128 && cb < 128) {
-        nb = 256 / cb;                                   // ~256 workgroups in the first level
+        nb = 256 / cb;                                   // ~256 workgroups
         if (nb > rows / 32) nb = rows / 32;              // at least 32 rows (2 per row group) per block
         if (nb < 1) nb = 1;
     }
-    const size_t cap = (size_t)facl_ws_bytes() / sizeof(double);
-    if (nb > 1 && (size_t)rows * V + (size_t)nb * V <= cap) {
+    const size_t cap = ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES) / sizeof(double);
+    if (nb > 1 && (size_t)rows * V + (size_t)nb * V <= cap && cb <= FACL_WS_TICKET_BYTES / 4) {
         const int rpb = (rows + nb - 1) / nb;
         nb = (rows + rpb - 1) / rpb;
         double* scratch = const_cast<double*>(part) + (size_t)rows * V;
-        hipLaunchKernelGGL(k_reduce_rows, dim3(cb, nb), dim3(1024), 0, st, part, rows, V, rpb, scratch);
-        hipLaunchKernelGGL(k_reduce_rows, dim3(cb, 1), dim3(1024), 0, st, scratch, nb, V, nb, out);
+        unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(const_cast<double*>(part)) + facl_ws_bytes() - FACL_WS_TICKET_BYTES);
+        // Default: TWO launches.  The single-launch form (FACL_REDUCE_1L=1) is bit-identical and was measured SLOWER on MI355X:
+        // 3.22 vs 3.10 ms per step, same box, alternating runs (gpurun_out/r4i) -- 17 reductions per step, ~7 us each.  Handing data
+        // from many workgroups to one inside a kernel needs a device-scope release / acquire (__threadfence), and with one L2
+        // per XCD (8 of them, not coherent with each other) that is an L2 write-back + invalidate -- far dearer than the ~1.5 us a
+        // kernel boundary costs in graph replay.  VERDICT r3 #5's "last-workgroup-done" folding is therefore not taken.
+        static const int one_level = getenv("FACL_REDUCE_1L") ? atoi(getenv("FACL_REDUCE_1L")) : 0;
+        if (!one_level) {
+            hipLaunchKernelGGL(k_reduce_rows, dim3(cb, nb), dim3(1024), 0, st, part, rows, V, rpb, scratch);
+            hipLaunchKernelGGL(k_reduce_rows, dim3(cb, 1), dim3(1024), 0, st, scratch, nb, V, nb, out);
+        } else {
+            hipLaunchKernelGGL(k_reduce_rows_t, dim3(cb, nb), dim3(1024), 0, st, part, rows, V, rpb, scratch, out, tickets);
+        }
     } else {
         hipLaunchKernelGGL(k_reduce_rows, dim3(cb, 1), dim3(1024), 0, st, part, rows, V, rows, out);
     }
     return facl_launch_status();
 }
 
-extern "C" int64_t facl_ws_bytes(void) { return (int64_t)FACL_WS_ROWS * 4608 * sizeof(double); }
+extern "C" int64_t facl_ws_bytes(void) { return (int64_t)FACL_WS_ROWS * 4608 * sizeof(double) + FACL_WS_TICKET_BYTES; }
 
 extern "C" int facl_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* bnc,

@@ -989,12 +989,12 @@ static int gemm_fwd_p(const float* a, int64_t M, int K, const float* W, int ldw,
         const long long big = (long long)((N + 127) / 128) * ((M + 127) / 128);
         const int rpp0 = (big >= 256 && !sbk_fits(g, 1)) ? 64 : 32;
         const long long prow0 = ((M + 2 * rpp0 - 1) / (2 * rpp0)) * 2;
-        if ((size_t)prow0 * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+        if ((size_t)prow0 * N * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     }
     int rc = pscale ? launch<KC, KC, true>(g, 1, st, &rpp) : launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
     const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
-    if ((size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    if ((size_t)prow * N * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     // rows of the last (partial) tile that no wave wrote hold stale data only if M % 64 != 0 for the last
     // wave-row; such partial rows contribute nothing because those waves stored s = sq = 0.
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
@@ -1013,11 +1013,11 @@ static int gemm_fwd_segmax_p(const float* a, int64_t M, int K, const float* W, i
     GemmArgs g{a, K, W, ldw, y, N, (int)M, N, K, bias, nullptr, nullptr, nullptr, nullptr, 0,
                sums ? (double*)ws : nullptr, K, sgn, ymax, arg, prec};
     int rpp = 64;
-    if (sums && (size_t)(((M + 127) / 128) * 2) * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    if (sums && (size_t)(((M + 127) / 128) * 2) * N * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     int rc = launch<KC, KC, false>(g, 1, st, &rpp);
     if (rc || !sums) return rc;
     const int prow = (int)((M + 2 * rpp - 1) / (2 * rpp)) * 2;
-    if ((size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    if ((size_t)prow * N * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     return facl_reduce_rows((const double*)ws, prow, 2 * N, sums, st);
 }
 

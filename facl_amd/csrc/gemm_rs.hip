@@ -851,7 +851,7 @@ extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* pl
     if (sgn && (M & 63)) return FACL_E_SHAPE;
     if (((uintptr_t)a | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
     const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
-    if (sums && (size_t)prow * N * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    if (sums && (size_t)prow * N * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(N, K, centers ? 1 : 0));
     RsArgs g{a, K, (int)M, K, (const uint4*)planes, N / 32, N, bias, pscale, pshift, centers, y, N,
@@ -886,7 +886,7 @@ extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, con
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
     const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
-    if ((size_t)prow * K * 2 * sizeof(double) > (size_t)facl_ws_bytes()) return FACL_E_SHAPE;
+    if ((size_t)prow * K * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(K, N, 0));
     RsArgs g{dy, N, (int)M, N, (const uint4*)planes, K / 32, K, nullptr, nullptr, nullptr, nullptr, da, K,

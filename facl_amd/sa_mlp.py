@@ -27,8 +27,9 @@ class _Workspace:
         if key not in cls._ws:
             n = _lib.load_library().facl_ws_bytes()
             cls._ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
+            cls._ws[key][-4096:].zero_()                 # ticket counters of the single-launch reduction (include/facl_hip.h)
         if _lib.POISON:
-            cls._ws[key].fill_(0xFF)                     # NaN bytes: every partial row a reduction reads must be rewritten
+            cls._ws[key][:-4096].fill_(0xFF)             # NaN bytes: every partial row a reduction reads must be rewritten
         return cls._ws[key]
 
 

@@ -77,7 +77,9 @@ int facl_group_clips(const float* clips, int B, int G, int N, int D, int S, int 
  * `bnc` is (5,C) float: mean, invstd, scale = gamma*invstd, shift = beta - mean*scale, sign(gamma).
  * running_mean / running_var (may both be NULL) are updated in place with `momentum` and the
  * unbiased variance, like F.batch_norm(training=True). */
-int64_t facl_ws_bytes(void);   /* size of the scratch buffer `ws` the reducing calls need */
+/* size of the scratch buffer `ws` the reducing calls need.  Its LAST 4096 bytes are ticket counters of the single-launch
+ * partial-row reduction: the caller zeroes them once after allocating the buffer; every call leaves them zero again. */
+int64_t facl_ws_bytes(void);
 /* aamax (or NULL): FACL_AMAX_WORDS uint32 that receive (in every slot) the bits of a rigorous BOUND of the layer's activation
  * max|gamma (y - mean) invstd + beta| over the batch: |gamma| sqrt(count - 1) sigma invstd + |beta| (Samuelson's inequality).
  * It is the fp16x3 operand scale of that activation (see "fp16x3 operand scales" below). */

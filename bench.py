@@ -33,8 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=("motion", "appearance", "dense"), default="motion",
-                    help="motion = BASELINE configs[1] (headline); appearance = configs[2]; dense = configs[4]")
+    ap.add_argument("--config", choices=("motion", "appearance", "dense", "extract"), default="motion",
+                    help="motion = BASELINE configs[1] (headline); appearance = configs[2]; dense = configs[4]; extract = the "
+                         "feature-extraction path (SURVEY 8 f-1: eval-mode encoder, extract_motion_feature.py), own metric string")
     ap.add_argument("--B", type=int, default=None, help="clips per GPU (default 32; dense: 8)")
     ap.add_argument("--T", type=int, default=None, help="views per clip (reference: gost / num_crop; default 24, dense 32)")
     ap.add_argument("--N", type=int, default=None, help="points per view (default 2048, dense 4096)")
@@ -49,9 +50,9 @@ def parse():
     ap.add_argument("--rehearse-dp", type=int, default=0,
                     help="1 (with --gpus 1): run the data-parallel code path on a 1-rank RCCL group -- every collective of the "
                          "N>1 step executes (as an identity) -- to time that path on a one-GPU box; never the headline")
-    ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the bounded CPU-baseline sample (default: the metric's own B = 32)")
     a = ap.parse_args()
-    dflt = {"motion": (32, 24, 2048), "appearance": (32, 24, 2048), "dense": (8, 32, 4096)}[a.config]
+    dflt = {"motion": (32, 24, 2048), "appearance": (32, 24, 2048), "dense": (8, 32, 4096), "extract": (32, 24, 2048)}[a.config]
     a.B = dflt[0] if a.B is None else a.B
     a.T = dflt[1] if a.T is None else a.T
     a.N = dflt[2] if a.N is None else a.N
@@ -164,6 +165,9 @@ def kernel_models(a, K=64):
         "facl_fps": dict(kernel="k_fps", flops=M * S * a.N * 9.0, pipe="valu", bytes=M * (a.N * D * 4.0 + S * 4.0)),
         "facl_group": dict(kernel="k_group", flops=M * S * a.N * 8.0, pipe="valu",
                            bytes=M * (a.N * D * 4.0 + S * K * D * 4.0 + S * 12.0)),
+        # eval mode, one kernel: x -> pooled; layers 2 and 3 on the MFMA (fp16x3), 64*D*4 B in and 1 KiB out per unit
+        "facl_sa_eval": dict(kernel="k_sa_eval", pipe="fp16x3", flops=nunits * 2.0 * 64 * (64 + 256) * 64,
+                             bytes=nunits * (64 * D * 4.0 + 1024.0)),
         "facl_sa_fwd2": dict(kernel="k_sa_fwd2" if sa_f32 else "k_sa_fwd2_sb", pipe="f32" if sa_f32 else "fp16x3" if fwd_h3 else "bf16x6",
                              flops=nunits * 2.0 * 64 * 64 * 64, bytes=nunits * (64 * D * 4.0 + y2)),
         "facl_sa_fwd3": dict(kernel="k_sa_fwd3_sb<fp16>" if a.config == "dense" else ("k_sa_fwd3" if sa_f32 else
@@ -296,6 +300,78 @@ def cpu_baseline(a):
                       f"(median {t:.2f} s/step, first {times[0]:.2f} s) of oracle.step.train_step"}
 
 
+def cpu_baseline_extract(a):
+    """Extraction configuration: oracle.step.extract_step (grouping + the encoder under eval() + the feature layout, torch-CPU
+    ops) on a bounded sample: `cpu_clips` clips of the same (T, N, D) shape, 1 warm-up + 3 timed passes."""
+    import numpy as np
+    import torch
+    from oracle import step as OS
+    from oracle import encoder as E
+    from oracle.weights import formula_state_dict
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    Bc, G = a.cpu_clips, a.T
+    sd = E.clone_state(formula_state_dict(a.D))
+    g = torch.Generator().manual_seed(0)
+    times = []
+    for it in range(4):
+        pts = OS.view_major(torch.rand(Bc, G, a.N, a.D, generator=g) - 0.5)
+        t0 = time.time()
+        OS.extract_step(sd, pts, Bc, G, 64, 64, 0.16 if a.N != 512 else 0.06)
+        times.append(time.time() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(Bc / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"B={Bc} clips x T={G} views x N={a.N} pts, D={a.D}: 1 warm-up + 3 timed passes "
+                      f"(median {t:.2f} s, first {times[0]:.2f} s) of oracle.step.extract_step"}
+
+
+def make_extract_step(a, dev, rank):
+    """bench.py --config extract: (step, eager step, batches, launch mode, workload, dtype, note).  One "step" = the per-batch
+    body of extract_motion_feature.py:171-182 on a batch resident in HBM: grouping -> encoder under eval() -> feature layout."""
+    import torch
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.extract_common import extract_batch
+    from facl_amd.train_common import synthetic_batch
+    opt = make_opt(a)
+    net = PointNet_Plus(opt, gost=a.T).to(dev).eval()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    batches = [synthetic_batch(a.B, a.T, a.N, a.D, dev, gen) for _ in range(2)]
+
+    def eager(batch, epoch=0):
+        with torch.no_grad():
+            f = extract_batch(net, batch, opt)
+        return f.sum(), None, None                       # (the bench reads a scalar back at the end, as for the loss)
+    mode, step = "eager", eager
+    if a.graph:
+        try:
+            static = batches[0].clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    eager(static)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = eager(static)
+
+            def step(batch, epoch=0):
+                static.copy_(batch, non_blocking=True)
+                g.replay()
+                return out
+            mode = "hipgraph"
+        except Exception as e:                            # never lose the measurement to a capture problem
+            print("graph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+            step = eager
+    workload = (f"feature extraction (extract_motion_feature.py:171-182), B={a.B}/GPU T={a.T} N={a.N} D={a.D}, S=64 K=64: kNN/radius "
+                f"grouping, cn3d_model_conbag encoder under eval() (net3DV_1 as ONE kernel, csrc/sa_eval.hip), (T+1)*512 features per clip")
+    note = ("fp32 storage and accumulation; the dense contractions on the 16-bit MFMAs with every fp32 operand split exactly into two "
+            "fp16 pieces of the operand times a power of two taken from its own maximum (fp16x3, DESIGN 3.0)")
+    return step, eager, batches, mode, workload, "f32", note
+
+
 def cpu_baseline_dense(a):
     """Dense configuration: oracle/dense.py (the 3-level encoder restated on torch-CPU ops, fp32) forward + losses +
     backward on a 2-clip sample of the same (T, N, D) shape, 1 warm-up + 1 timed pass.  No optimiser step (the oracle
@@ -351,6 +427,8 @@ def main():
     if a.config == "dense":
         from facl_amd import dense as fdense
         step, eager_step, batches, mode, workload, dtype, dtype_note = fdense.make_bench_step(a, dev, rank, world)
+    elif a.config == "extract":
+        step, eager_step, batches, mode, workload, dtype, dtype_note = make_extract_step(a, dev, rank)
     else:
         from facl_amd.cn3d_model_conbag import PointNet_Plus
         from facl_amd.train_common import ContrastiveStep, GraphedStep, GraphCaptureFailed, synthetic_batch, appearance_batch
@@ -453,8 +531,12 @@ def main():
         if a.config == "dense":
             out["metric"] = ("dense-config contrastive-step clips/sec (BASELINE configs[4]: N=4096 T=32, 3-level set "
                              "abstraction, fp16 MFMA point-MLP)")
+        if a.config == "extract":
+            out["metric"] = "feature-extraction clips/sec (B=32,T=24,N=2048), eval-mode encoder (SURVEY 8 f-1: extract_motion_feature.py)"
+            out.pop("final_loss", None)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_dense(a) if a.config == "dense" else cpu_baseline(a)
+            out["cpu_baseline"] = cpu_baseline_dense(a) if a.config == "dense" else cpu_baseline_extract(a) if a.config == "extract" \
+                else cpu_baseline(a)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -47,6 +47,7 @@ SIGNATURES = {
     "facl_sa_fwd3_h3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3_f16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_pool": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
+    "facl_sa_eval": [c_p, c_l, c_i] + [c_p] * 12,
     "facl_rows_stats": [c_p, c_l, c_i, c_p, c_p, c_p],
     "facl_rows_bn_relu": [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_segmax": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],

@@ -10,6 +10,8 @@ import torch
 from . import _lib
 
 _FWD_H3 = __import__("os").environ.get("FACL_FWD_H3", "1") != "0"
+# eval mode through the ONE-kernel path (csrc/sa_eval.hip); FACL_EVAL_FUSED=0: the training passes with folded constants (A/B)
+_EVAL_FUSED = __import__("os").environ.get("FACL_EVAL_FUSED", "1") != "0"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 UNIT = 64
@@ -154,6 +156,19 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
     l1tab = _lib.empty((64, 8), dtype=torch.float32, device=dev)
     _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(p["b1"]), D, _lib.ptr(bnc1[2]), _lib.ptr(bnc1[3]),
                                  _lib.ptr(l1tab), _lib.ptr(xa), None if xa is None else _lib.ptr(amax[1]), st), "facl_sa_l1tab")
+    if not training and _EVAL_FUSED and precision in ("f32", "x3b") and _FWD_H3:
+        # eval mode = the extraction path (extract_motion_feature.py:143-221): every BatchNorm is a constant affine, so the whole
+        # block is ONE kernel per unit, x -> pooled, with nothing stored in between (csrc/sa_eval.hip)
+        bnc2 = _bn_eval(64, p["g2"], p["be2"], p["rm2"], p["rv2"])
+        bnc3 = _bn_eval(256, p["g3"], p["be3"], p["rm3"], p["rv3"])
+        pooled_u = _lib.empty((nunits, 256), dtype=torch.float32, device=dev)
+        with _lib.timed("facl_sa_eval"):
+            _lib.check(lib.facl_sa_eval(_lib.ptr(x_rows), nunits, D, _lib.ptr(l1tab), _lib.ptr(W2), _lib.ptr(p["b2"]),
+                                        _lib.ptr(bnc2[2]), _lib.ptr(bnc2[3]), _lib.ptr(W3), _lib.ptr(p["b3"]), _lib.ptr(bnc3[2]),
+                                        _lib.ptr(bnc3[3]), _lib.ptr(pooled_u), _lib.ptr(amax[1]), st), "facl_sa_eval")
+        if R > 1:      # a group spans R units: BN + ReLU are monotone per channel, so the group's feature is the maximum of its units'
+            pooled_u = pooled_u.view(nunits // R, R, 256).max(dim=1).values.contiguous()
+        return pooled_u, {"amax": None, "nunits": nunits, "D": D, "R": R, "x_rows": x_rows}
     y2f = _lib.empty(nunits * UNIT * 64, dtype=torch.float32, device=dev)
     sums2 = _lib.empty((64, 2), **f64) if training else None
     with _lib.timed("facl_sa_fwd2"):
@@ -316,7 +331,8 @@ class SAMLPFunction(torch.autograd.Function):
         p.update(state["buffers"])
         pooled, c = sa_mlp_forward(x_rows, p, state["training"], state.get("reduce_fn"), K=state.get("K", UNIT),
                                    precision=state.get("precision", "f32"))
-        state["pooled_amax"] = c["amax"][3]               # max(pooled): the fp16x3 scale of the GEMM that consumes the features
+        # max(pooled): the fp16x3 scale of the GEMM that consumes the features (the fused eval kernel keeps none: measured there)
+        state["pooled_amax"] = None if c.get("amax") is None else c["amax"][3]
         ctx.c, ctx.p, ctx.x_rows, ctx.reduce_fn = c, p, x_rows, state.get("reduce_fn")
         ctx.training = state["training"]
         return pooled

@@ -133,6 +133,13 @@ int facl_sa_fwd3_h3(const float* y2f, int64_t nunits, const float* scale2, const
  * bits of max(pooled) */
 int facl_sa_pool(const float* ymax, int64_t rows, int C, const float* scale, const float* shift,
                  float* pooled, uint32_t* amax, void* stream);
+/* net3DV_1 in EVAL mode as ONE kernel (csrc/sa_eval.hip; SURVEY 8 f-1: extract_motion_feature.py:143-221 runs the encoder under
+ * eval(), every BatchNorm a constant affine): x (nunits*64, D) grouped rows -> pooled (nunits, 256); nothing else is stored (no y2
+ * tile, no statistics, no argmax).  l1tab from facl_sa_l1tab with BN1's eval constants (and xamax -> a1amax); scale2 / shift2 (64),
+ * scale3 / shift3 (256): rows 2 and 3 of facl_bn_eval_consts. */
+int facl_sa_eval(const float* x, int64_t nunits, int D, const float* l1tab, const float* W2, const float* b2,
+                 const float* scale2, const float* shift2, const float* W3, const float* b3, const float* scale3,
+                 const float* shift3, float* pooled, const uint32_t* a1amax, void* stream);
 /* ---- fp16x3 operand scales: measured maxima for operands no BatchNorm bounds ----
  *   facl_absmax          raises the slots of `amax` (FACL_AMAX_WORDS uint32, zeroed by the caller or pre-seeded) to max|x|
  *   facl_rows_act_amax   the same for max relu(scale[c] y[r][c] + shift[c]) of a (R,C) array (eval-mode layers: running

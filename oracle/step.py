@@ -87,3 +87,14 @@ def train_step(sd, opt, points_vm, B, G, S, K, r2, order, epoch=0, grouped=None)
         sd[k].grad = None
     return dict(loss=float(loss), loss_c=float(loss_c), loss_circle=float(loss_circle), grads=grads,
                 outputs=(x.detach(), code.detach(), x_nor.detach(), x_global.detach()))
+
+
+def extract_step(sd, points_vm, B, G, S, K, r2):
+    """The per-batch body of /root/reference/training_code/extract_motion_feature.py:171-182 on the CPU: grouping, the
+    encoder under eval() (BatchNorm from its running statistics), cat((x, x_global), 0) -> (B, (G+1)*512) features
+    (save_single_feature's layout, :217-221).  The ``cpu_baseline`` of `bench.py --config extract`."""
+    with torch.no_grad():
+        _, xt, yt = group_torch(points_vm, S, K, r2)
+        x, _, _, x_global = E.encoder_forward(sd, xt, yt, G, training=False)
+        feat = torch.cat((x, x_global), dim=0)
+        return feat.reshape(G + 1, B, 512).permute(1, 0, 2).reshape(B, (G + 1) * 512)

@@ -72,6 +72,41 @@ def test_sa_forward_vs_oracle(D, neg, training):
         assert int(ctx["arg"].max()) < 64
 
 
+@pytest.mark.parametrize("D,neg,K", [(4, False, 64), (3, True, 64), (4, False, 128), (3, False, 16)])
+def test_sa_eval_one_kernel_vs_training_kernels_and_fp64(D, neg, K):
+    """eval mode (the extraction path) is ONE kernel, x -> pooled (csrc/sa_eval.hip), with a2 scaled by the power
+    of two of each unit's own maximum.  Against the fp64 oracle (2e-5 kernel-level bar, as the training passes) and against the
+    training passes run with folded constants (the rounds 1-3 eval path: same arithmetic up to the operand scales)."""
+    from facl_amd import sa_mlp, utils_my
+    from oracle.weights import formula_state_dict
+    torch.manual_seed(D + K)
+    M, N, S = 6, 512, 1024 // K if K > 64 else 64
+    pts = (torch.rand(M, N, D) - 0.5)
+    xt, yt = utils_my.knn_radius_group(pts.to(DEV), S, K, 0.1)
+    sd = formula_state_dict(D, neg_gamma=neg)
+    p = _params(sd, DEV)
+    x_rows = xt.permute(0, 2, 3, 1).reshape(-1, D).contiguous()
+    assert sa_mlp._EVAL_FUSED
+    fused, _ = sa_mlp.sa_mlp_forward(x_rows, p, False, K=K)
+    sa_mlp._EVAL_FUSED = False
+    try:
+        unfused, _ = sa_mlp.sa_mlp_forward(x_rows, p, False, K=K)
+    finally:
+        sa_mlp._EVAL_FUSED = True
+    ref64, _ = _oracle_pooled(sd, xt.cpu(), False, torch.float64)
+    e_f, e_u = max_rel_rows(fused.cpu().numpy(), ref64.numpy()), max_rel_rows(unfused.cpu().numpy(), ref64.numpy())
+    print(f"one kernel vs fp64 {e_f:.2e}   training passes with folded constants vs fp64 {e_u:.2e}")
+    assert fused.shape == unfused.shape == (M * S, 256)
+    assert e_f < 2e-5 and e_f < 3 * e_u + 2e-6
+    # a NaN coordinate poisons exactly its own group (MaxPool2d propagates NaN; the reference's features would be NaN there)
+    x_bad = x_rows.clone()
+    x_bad[5 * K + 3, 1] = float("nan")
+    bad, _ = sa_mlp.sa_mlp_forward(x_bad, p, False, K=K)
+    assert not torch.isfinite(bad[5]).any()
+    keep = [i for i in range(M * S) if i != 5]
+    assert torch.equal(bad[keep], fused[keep])
+
+
 def test_sa_forward_c1_golden():
     """Stage pin against the reference's own net3DV_1 output (forward hook tap in make_goldens)."""
     from facl_amd import sa_mlp, utils_my

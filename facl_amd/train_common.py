@@ -53,7 +53,13 @@ def build_parser(default_branch):
     p.add_argument('--save_label_dir', type=str, default='../ntu/ntu60_new2/labels/')
     p.add_argument('--branch_choose', type=str, default=default_branch)
     # NEW
-    p.add_argument('--synthetic', type=int, default=1, help='NEW: 1 = iid U[-0.5,0.5) clouds (no NTU data here)')
+    p.add_argument('--synthetic', type=int, default=1,
+                   help='NEW: 1 = iid U[-0.5,0.5) clouds (no NTU data here); 2 = synthetic RAW clips (the four (rows, 8) clouds the '
+                        'loader reads per video) through the GPU view construction (facl_amd.views.build_views = the dataset '
+                        "class's get_data_train, cn3D_data_set.py:285-350): needs --num_crop 10 --SAMPLE_NUM 512 --INPUT_FEATURE_NUM 4")
+    p.add_argument('--view_rng', type=str, default='numpy', choices=('numpy', 'device'),
+                   help='NEW (--synthetic 2): numpy = draw the view construction\'s random numbers on the host in the reference\'s '
+                        'NumPy order; device = draw them on the GPU (same distributions, another stream)')
     p.add_argument('--num_crop', type=int, default=10, help='NEW: views per clip (literal 10 at :189)')
     p.add_argument('--steps_per_epoch', type=int, default=8, help='NEW: synthetic iterations per epoch')
     p.add_argument('--group_radius', type=float, default=None,
@@ -129,7 +135,6 @@ class ContrastiveStep:
 
     def __call__(self, out_points, epoch=0, order=None):
         netR, G = self.netR, self.G
-        B, G_, N, D = out_points.shape
         if order is None:
             order = np.arange(0, G, 1)
             np.random.shuffle(order)                                               # :297-298
@@ -139,8 +144,20 @@ class ContrastiveStep:
         return self.run(out_points, order)
 
     def run(self, out_points, order):
-        """Device-only body (no host round trips): this is what GraphedStep captures into a HIP graph."""
+        """Device-only body (no host round trips): this is what GraphedStep captures into a HIP graph.
+        `out_points`: the loader's clip-major (B,G,N,D) batch, or -- 3-dimensional -- the view-major (G*B,N,D) rows that
+        facl_amd.views.build_views writes directly (the permute + reshape of :226 already done)."""
         netR, G = self.netR, self.G
+        if out_points.dim() == 3:
+            M_, N, D = out_points.shape
+            B = M_ // G
+            data1 = out_points if out_points.dtype == torch.float32 else out_points.float()
+            if self.fps_reorder:
+                from .fps import fps_sample_data
+                data1 = fps_sample_data(data1, self.opt.sample_num_level1,
+                                        start_idx=torch.zeros(data1.shape[0], dtype=torch.int32, device=data1.device))
+            xt, yt = self.group(data1)
+            return self._encode_and_step(xt, yt, B, order)
         B, G_, N, D = out_points.shape
         if self.fps_reorder or out_points.dtype != torch.float32 or (self.r2 is None and self.opt.SAMPLE_NUM == 512):
             data1 = out_points.permute(1, 0, 2, 3).reshape(-1, N, D).float()      # :226-228 (view-major rows)
@@ -151,6 +168,10 @@ class ContrastiveStep:
             xt, yt = self.group(data1)
         else:
             xt, yt = self.group(out_points)        # clip-major batch: the grouping kernel reads view-major in place
+        return self._encode_and_step(xt, yt, B, order)
+
+    def _encode_and_step(self, xt, yt, B, order):
+        netR, G = self.netR, self.G
         x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
         x_keys = fdist.all_gather_view_major(x, G)
         off = self.rank * B
@@ -366,6 +387,7 @@ def run(default_branch, ckpt_pattern, args=None):
     step = ContrastiveStep(netR, optimizer, opt, num_crop, opt.group_radius, bool(opt.fps_reorder), opt.swa_if, opt.cld_if)
     gen = torch.Generator(device=device)
     gen.manual_seed(1000 + rank)
+    view_rng = np.random.RandomState(2000 + rank)         # --synthetic 2: the generator the view construction draws from
 
     run_step = step
     for epoch in range(0, opt.nepoch):
@@ -374,10 +396,23 @@ def run(default_branch, ckpt_pattern, args=None):
             g["lr"] = lr_for_epoch(opt.learning_rate, epoch)
         loss_sigma, t0 = 0.0, time.time()
         for i in range(opt.steps_per_epoch):
-            if not opt.synthetic:
-                raise RuntimeError("only --synthetic 1 is supported: the NTU dataset pipeline "
-                                   "(cn3D_data_set.py) is outside this repository's scope")
-            out_points = synthetic_batch(opt.batchSize, num_crop, opt.SAMPLE_NUM, opt.INPUT_FEATURE_NUM, device, gen)
+            if opt.synthetic == 2:
+                # the loop body from the loader's output on (:224-228): raw clips -> the 10 augmented views of every clip,
+                # built on the GPU in one launch, view-major float32 (facl_amd/views.py; draws in the reference's NumPy order)
+                if (num_crop, opt.SAMPLE_NUM, opt.INPUT_FEATURE_NUM) != (10, 512, 4):
+                    raise RuntimeError("--synthetic 2 builds the reference's 10 views of 512 points x 4 channels: "
+                                       "use --num_crop 10 --SAMPLE_NUM 512 --INPUT_FEATURE_NUM 4")
+                from .views import build_views, synthetic_raw_clip
+                base = ((epoch * opt.steps_per_epoch + i) * world + rank) * opt.batchSize
+                clips = [synthetic_raw_clip(base + b) for b in range(opt.batchSize)]
+                # --view_rng numpy: the reference's NumPy stream (a seed reproduces its views; ~0.2 ms of host draws per clip);
+                # device: the same distributions drawn by a torch generator on the GPU (no per-clip host work)
+                out_points = build_views(clips, view_rng, device, device_rng=gen if opt.view_rng == "device" else None)
+            elif opt.synthetic == 1:
+                out_points = synthetic_batch(opt.batchSize, num_crop, opt.SAMPLE_NUM, opt.INPUT_FEATURE_NUM, device, gen)
+            else:
+                raise RuntimeError("only --synthetic 1 / 2 are supported: the NTU dataset file pipeline "
+                                   "(cn3D_data_set.py: video lists, .npy loading) is outside this repository's scope")
             if run_step is step and opt.graph and not (opt.swa_if or opt.cld_if):
                 try:                                     # capture on the first batch; state restored: same trajectory as eager
                     run_step = GraphedStep(step, out_points, num_crop, restore=True)
@@ -390,7 +425,12 @@ def run(default_branch, ckpt_pattern, args=None):
                     opt.graph = 0
             loss, _, _ = run_step(out_points, epoch)
             torch.cuda.synchronize()
-            loss_sigma += loss.item()
+            lv = loss.item()
+            if lv != lv or lv in (float("inf"), float("-inf")):
+                # inputs / a checkpoint with NaN or inf (the arithmetic itself has no range limit any more: DESIGN 3.0):
+                # stop here instead of training on garbage
+                raise FloatingPointError("non-finite loss %r at epoch %d, iteration %d" % (lv, epoch, i))
+            loss_sigma += lv
         clips = opt.batchSize * opt.steps_per_epoch * world / (time.time() - t0)
         logging.info('{} --epoch{} ==Average loss:{}'.format('Valid', epoch, loss_sigma / (i + 1)))
         if rank == 0:

@@ -71,6 +71,36 @@ def test_train_entry_graph_mode_follows_the_eager_trajectory(tmp_path):
     assert int(sds[0]["net3DV_1.1.num_batches_tracked"]) == 6
 
 
+def test_train_entry_from_raw_clips_through_gpu_view_construction(tmp_path):
+    """SURVEY 8 f-3 wired into the entry (--synthetic 2): raw clips -> facl_amd.views.build_views (the dataset class's 10 views,
+    one HIP launch, draws in the reference's NumPy order) -> the loop body of cn3d_train_motion_GL.py:224-335 on the view-major
+    rows.  The views the step consumed equal oracle/views.py for the same clips and generator; graph replay == eager."""
+    from facl_amd import cn3d_train_motion_GL as train
+    from facl_amd.views import build_views, synthetic_raw_clip
+    from oracle import views as OV
+    args = ["--batchSize", "4", "--nepoch", "1", "--steps_per_epoch", "3", "--num_crop", "10", "--SAMPLE_NUM", "512",
+            "--INPUT_FEATURE_NUM", "4", "--synthetic", "2"]
+    sds = []
+    for gflag in ("1", "0"):
+        net = train.main(args + ["--graph", gflag, "--save_root_dir", str(tmp_path / ("ck" + gflag))])
+        sds.append({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    for k, v in sds[0].items():
+        assert torch.isfinite(v.float()).all(), k
+        if v.is_floating_point():
+            assert torch.allclose(v, sds[1][k], rtol=1e-5, atol=1e-7), k
+    assert int(sds[0]["net3DV_1.1.num_batches_tracked"]) == 3
+    # the first batch the entry built: rank 0, iteration 0 -> clips seeded 0..3, generator RandomState(2000)
+    clips = [synthetic_raw_clip(b) for b in range(4)]
+    got = build_views(clips, np.random.RandomState(2000)).cpu().numpy()
+    rng = np.random.RandomState(2000)
+    want = OV.collate_view_major([OV.get_item(rng, *c) for c in clips])
+    assert got.shape == (40, 512, 4)
+    np.testing.assert_allclose(got, want, rtol=0, atol=np.spacing(np.float32(1.0)))
+    with pytest.raises(RuntimeError, match="num_crop 10"):
+        train.main(["--batchSize", "2", "--nepoch", "1", "--steps_per_epoch", "1", "--num_crop", "4", "--synthetic", "2",
+                    "--save_root_dir", str(tmp_path / "bad")])
+
+
 def test_graph_replay_equals_eager():
     from facl_amd.cn3d_model_conbag import PointNet_Plus
     from facl_amd.train_common import ContrastiveStep, GraphedStep

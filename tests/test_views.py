@@ -71,3 +71,34 @@ def test_build_views_matches_reference_golden(seed):
             else:
                 np.testing.assert_array_equal(a, w)
     assert rng.rand() == float(g[f"seed{seed}/next_rand"])
+
+
+@pytest.mark.gpu
+def test_build_views_device_rng_has_the_reference_distributions():
+    """device_rng mode draws on the GPU (another stream than NumPy's): every view must still be what get_data_train builds --
+    rows of the right source cloud, jitter clipped at 0.05 with sigma 0.01, x mirrored, rotations norm-preserving about y,
+    temporal views from rows with a non-zero temporal channel."""
+    import torch
+    from facl_amd.views import build_views
+    B = 6
+    clips = [_clip(10 + b, np.float32, P=700 + 13 * b, Kp=300 + b, R1=400, R2=100) for b in range(B)]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    out = build_views(clips, device_rng=gen).cpu().numpy().reshape(10, B, 512, 4)
+    out2 = build_views(clips, device_rng=gen).cpu().numpy().reshape(10, B, 512, 4)
+    assert not np.array_equal(out, out2)                                     # the generator advances
+    for b, (pts, key, r1, r2) in enumerate(clips):
+        def rows_of(a, src, cols=(0, 1, 2, 3)):
+            s = {tuple(r) for r in src[:, list(cols)].astype(np.float32)}
+            return all(tuple(r) in s for r in a)
+        assert rows_of(out[0, b], pts) and rows_of(out[8, b], r1) and rows_of(out[9, b], r2)       # plain gathers
+        assert rows_of(out[6, b], pts[pts[:, 4] != 0], (0, 1, 2, 4)) and rows_of(out[7, b], pts[pts[:, 7] != 0], (0, 1, 2, 7))
+        assert rows_of(out[2, b][:, 3:], key, (3,))                                                  # 4th channel untouched
+        # key-point view: xyz = a source row + clipped jitter
+        d = np.abs(out[2, b][:, None, :3] - key[None, :, :3].astype(np.float32)).max(-1).min(1)
+        assert d.max() <= 0.05 + 1e-6 and 0.004 < d.mean() < 0.03
+        # rotated views: |(x, z)| and y of SOME jittered source row are preserved -> y within jitter of a source y
+        dy = np.abs(out[4, b][:, None, 1] - pts[None, :, 1].astype(np.float32)).min(1)
+        assert dy.max() <= 0.05 + 1e-6
+    # reversed views: x mirrored -> the mean of x flips sign relative to the source's (sources are not centred per clip)
+    assert np.isfinite(out).all()

@@ -451,7 +451,8 @@ def main():
         if use_graph:
             try:
                 step = GraphedStep(step, batches[0], a.T)
-                mode = "hipgraph" if step.segments is None else \
+                mode = ("hipgraph (OPT-IN FACL_DP_GRAPH=full: collectives captured inside the graph; replay validated against one eager step)"
+                        if getattr(step, "full_dp_graph", False) else "hipgraph") if step.segments is None else \
                     "hipgraph segments (%d graphs, %d eager collectives between them; replay validated against one eager step)" % (
                         step.segments.n_graphs, len(step.segments.items) - step.segments.n_graphs)
             except GraphCaptureFailed as e:

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(1024) void k_reduce_rows_t(const double* __restrict
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st) {
     const int cb = (V + 63) / 64;
     int nb = 1;
-    if (rows >= 128 && cb < 128) {
+    // two levels only when one workgroup per 64 columns would have to walk many rows (FACL_REDUCE_MIN_ROWS: A/B knob)
+    static const int min_rows = getenv("FACL_REDUCE_MIN_ROWS") ? atoi(getenv("FACL_REDUCE_MIN_ROWS")) : 128;
+    if (rows >= min_rows && cb < 128) {
         nb = 256 / cb;                                   // ~256 workgroups
         if (nb > rows / 32) nb = rows / 32;              // at least 32 rows (2 per row group) per block
         if (nb < 1) nb = 1;

@@ -243,7 +243,7 @@ class GraphedStep:
         snap = self._snapshot()
         try:
             self._capture(distributed, dev)
-            if validate and self.segments is not None:
+            if validate and (self.segments is not None or getattr(self, "full_dp_graph", False)):
                 self._validate()
         except Exception:
             self.graph = self.segments = None
@@ -291,7 +291,25 @@ class GraphedStep:
         # would run ahead of the running-statistics updates: restore them afterwards.  NOTE: the 3 warm-up calls above
         # are REAL optimizer steps on `example_points` (they also settle the allocator and Adam's lazy state).
         saved = [(m, m.steps) for m in self._bn_modules()]
-        if distributed:
+        if distributed and os.environ.get("FACL_DP_GRAPH", "segments") == "full":
+            # OPT-IN experiment (never the default): the collectives are captured INSIDE one graph (torch's RCCL process group
+            # joins a stream capture the way it does on NCCL), so the data-parallel step has no cut at all.  Rehearsed with a
+            # 1-rank RCCL group only (bench.py --rehearse-dp 1); with N > 1 ranks it has never run: the validation below
+            # (eager step == replayed step, voted across ranks) is what stands between a wrong replay and the measurement.
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph, stream=s):
+                    self.out = step.run(self.points, self.order)
+            except Exception as e:
+                ok = False
+                err = "%s: %s" % (type(e).__name__, e)
+            else:
+                ok, err = True, ""
+            if not fdist.vote(ok):
+                raise GraphCaptureFailed("full-graph capture of the data-parallel step failed on some rank%s" % (" (here: %s)" % err if err else ""))
+            self.graph = graph
+            self.full_dp_graph = True
+        elif distributed:
             # data parallel: the capture is cut at every collective (facl_amd/dist.py: GraphSegments) -- kernel segments
             # replay as graphs, the collectives in between are ordinary eager RCCL calls on the same stream
             rec = fdist.GraphSegments()
@@ -323,7 +341,10 @@ class GraphedStep:
         snap = self._snapshot()
         loss_e = float(step.run(self.points, self.order)[0])
         self._restore(snap)
-        self.segments.replay()
+        if self.segments is not None:
+            self.segments.replay()
+        else:
+            self.graph.replay()
         loss_g = float(self.out[0])
         self._restore(snap)
         ok = loss_e == loss_e and abs(loss_e - loss_g) <= 1e-5 * abs(loss_e)

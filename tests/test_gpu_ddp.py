@@ -335,3 +335,57 @@ def test_segmented_graph_step_equals_eager_step_under_data_parallelism(backend, 
         for a, b in zip(l_eager, l_graph):
             assert abs(a - b) <= 1e-5 * abs(a), (l_eager, l_graph)
         assert worst < 1e-4
+
+
+def _worker_full_graph(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", FACL_DP_GRAPH="full")
+    import torch.distributed as dist
+    from facl_amd import dist as fdist
+    import facl_amd.train_common as TC
+    from facl_amd.cn3d_model_conbag import PointNet_Plus
+    from facl_amd.optim import FusedAdam
+    from oracle.weights import formula_state_dict
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    fdist.is_distributed = lambda: True                          # force every collective on with a 1-rank RCCL group
+    TC.fdist.is_distributed = fdist.is_distributed
+    try:
+        torch.manual_seed(3)
+        G, B, N, D = 4, 2, 512, 4
+        clips = [(torch.rand(B, G, N, D) - 0.5).cuda() for _ in range(3)]
+        order = np.array([2, 0, 3, 1])
+        out = []
+        for graphed in (False, True):
+            net = PointNet_Plus(_opt(D, B, N), gost=G)
+            net.load_state_dict({k: torch.as_tensor(v) for k, v in formula_state_dict(D).items()})
+            net = net.cuda().train()
+            net.bn_reduce_fn = fdist.make_bn_reduce_fn()
+            step = TC.ContrastiveStep(net, FusedAdam(net.parameters(), lr=3e-4, betas=(0.5, 0.999), eps=1e-6), _opt(D, B, N), G)
+            if graphed:
+                step = TC.GraphedStep(step, clips[0], G, restore=True)
+                assert step.segments is None and step.full_dp_graph
+            out.append([float(step(c, epoch=0, order=order)[0].item()) for c in clips])
+        q.put(("ok", out))
+    except BaseException:
+        import traceback
+        q.put(("error", traceback.format_exc()))
+    dist.destroy_process_group()
+
+
+def test_optin_full_graph_capture_of_the_data_parallel_step():
+    """FACL_DP_GRAPH=full (opt-in, never the default): the data-parallel step with its 19 collectives captured INSIDE one HIP
+    graph (torch's RCCL process group joins the stream capture) -- no cut, no eager collective.  On the real RCCL backend with
+    a forced 1-rank group: three optimizer steps equal the eager sharded step (GraphedStep validated the replay against one
+    eager step before handing it out)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_full_graph, args=(30100 + (os.getpid() % 2000), q))
+    p.start()
+    status, payload = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", payload
+    eager, graph = payload
+    print("eager", eager, "full graph", graph)
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-5 * abs(a)

@@ -467,13 +467,14 @@ def main():
                     f"kNN/radius grouping, full cn3d_model_conbag encoder, global+circle loss, backward, Adam")
         dtype = {"f32": "f32", "x3": "bf16x3", "x3b": "f32 (backward GEMMs bf16x3)"}[a.precision]
         dtype_note = ("fp32 storage and accumulation; dense contractions on the 16-bit MFMAs with every fp32 operand split "
-                      "exactly: fp16x3 (two fp16 pieces of the power-of-two-scaled operand, 3 products per multiply-add) in the "
-                      "row-streamed tail GEMMs (forward, dgrad, widest wgrad) and the 64->256 set-abstraction layer, bf16x6 (three "
-                      "bf16 pieces, 6 products) elsewhere; both measure at or below torch's fp32 matmul error against fp64 "
-                      "(DESIGN.md 3.0).  Measured parity at this size (tests/test_gpu_headline.py, one full step vs a "
-                      "torch-fp64 evaluation): features 4.5e-6 / 4.8e-6 (x / x_global, worst row), losses 1e-7, BN running "
-                      "statistics < 1e-5; the reference's own fp32 run sits 4e-5..1.5e-3 from the same fp64 truth "
-                      "(DESIGN.md section 2).  FACL_FWD_H3=0 FACL_BWD_H3=0 select bf16x6 everywhere")
+                      "exactly: fp16x3 (two fp16 pieces of the operand times a power of two taken from the operand's own maximum / "
+                      "bound -- no fixed scale, no range contract since round 4 --, 3 products per multiply-add) in the set-abstraction "
+                      "passes and the row-streamed tail GEMMs (forward, dgrad, wgrad), bf16x6 (three bf16 pieces, 6 products) in the "
+                      "~800-row FC-head / loss GEMMs; both measure at or below torch's fp32 matmul error against fp64 (DESIGN.md 3.0).  "
+                      "Measured parity at this size (tests/test_gpu_headline.py, one full step vs a torch-fp64 evaluation): features "
+                      "4.5e-6 / 4.8e-6 (x / x_global, worst row), losses 1e-7, BN running statistics < 1e-5, every parameter gradient "
+                      "<= 1.1e-5 of fp64 with the discrete decisions (max-pool argmax, ReLU signs) pinned; the reference's own fp32 run "
+                      "sits 4e-5..1.5e-3 from the same fp64 truth (DESIGN.md section 2).  FACL_FWD_H3=0 FACL_BWD_H3=0 select bf16x6 everywhere")
         if a.precision == "x3":
             dtype_note = ("OPT-IN --precision x3 (not the headline): fp32 storage and accumulation; the tail / loss GEMMs and the "
                           "64->256 set-abstraction layer keep two bf16 pieces per operand, three products per multiply-add "

@@ -11,6 +11,21 @@ static inline int facl_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `done` = one flag per device ordinal (a
+// process may drive several devices through this C ABI; a forward on the main thread can race a backward on the autograd
+// thread, in which case the attribute is merely set twice).  Returns a HIP error code or 0.
+static inline int facl_set_dynamic_lds(bool (&done)[64], const void* const* fns, int nfns, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return 0;
+    for (int i = 0; i < nfns; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    done[dev] = true;
+    return 0;
+}
+
 // "sign of gamma" arguments (facl_sa_fwd3, facl_gemm_fwd_segmax): callers may pass the BatchNorm weight itself -- the
 // kernels only use its sign, with sign(0) = +1 (a +-1 array, the round-1 convention, maps onto itself)
 __device__ __forceinline__ float sgn_of(float g) { return g < 0.f ? -1.f : 1.f; }

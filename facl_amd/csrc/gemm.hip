@@ -866,13 +866,9 @@ int launch_sbk(const GemmArgs& g, int nz, hipStream_t st) {
     constexpr int TILE_F = NP * 2 * 64 * SBROW * 2 / 4, STG = 4 * 32 * 36;
     constexpr int F = SBK_KG * TILE_F > STG + (SBK_KG - 1) * 4096 ? SBK_KG * TILE_F : STG + (SBK_KG - 1) * 4096;
     constexpr int lds = F * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static bool attr_done[64] = {};                   // per template instantiation and device ordinal
+    const void* fns[1] = {(const void*)k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>};
+    if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, lds)) return rc;
     dim3 grid((g.NJ + 63) / 64, (g.MI + 63) / 64, nz);
     hipLaunchKernelGGL((k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>), grid, dim3(256 * SBK_KG), lds, st, g);
     return facl_launch_status();

@@ -689,12 +689,9 @@ extern "C" int facl_sa_bwd1(const float* y2f, int64_t nunits, const float* bnc2,
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
     const size_t lds = (1024 + 4096 + 80) * sizeof(float4) + 4 * 64 * TP * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_sa_bwd1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static bool attr_done[64] = {};
+    const void* fns[1] = {(const void*)k_sa_bwd1};
+    if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, (int)lds)) return rc;
     hipLaunchKernelGGL(k_sa_bwd1, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, bnc2, G3, h3, W3, coef, arg, dz2f,
                        (double*)ws, a2amax);
     int rc = facl_launch_status();
@@ -709,12 +706,9 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
     const size_t lds = 32 * sizeof(float4) + (256 * 65 + 64 * 64 + 64 + 4 * 64 * TP) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_sa_bwd_w3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static bool attr_done[64] = {};
+    const void* fns[1] = {(const void*)k_sa_bwd_w3};
+    if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, (int)lds)) return rc;
     hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, a2amax);
     int rc = facl_launch_status();
     if (rc) return rc;
@@ -740,13 +734,9 @@ extern "C" int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x,
     }
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
     const size_t lds = (1024 + 128 + 64) * sizeof(float4) + 4 * (2 * 64 * TQ + 64 * 8) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_sa_bwd2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_sa_bwd2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
-        attr_done = true;
-    }
+    static bool attr_done[64] = {};
+    const void* fns[2] = {(const void*)k_sa_bwd2<4>, (const void*)k_sa_bwd2<3>};
+    if (int rc = facl_set_dynamic_lds(attr_done, fns, 2, (int)lds)) return rc;
     if (D == 4) hipLaunchKernelGGL((k_sa_bwd2<4>), dim3(grid), dim3(256), lds, st, dz2f, y2f, x, (int)nunits, bw2, W2, l1tab, (double*)ws);
     else hipLaunchKernelGGL((k_sa_bwd2<3>), dim3(grid), dim3(256), lds, st, dz2f, y2f, x, (int)nunits, bw2, W2, l1tab, (double*)ws);
     int rc = facl_launch_status();

@@ -60,7 +60,9 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const char* p_lo, const char* p_h
 // two that puts the maximum of the wave's half unit in [2^13, 2^14) (one DPP reduction per half unit, no LDS, no host).  The
 // da1 tiles are scaled back when they are consumed; dW2's contribution of a half unit is accumulated in a temporary tile
 // and added to the running sums with the inverse scale, so half units of different magnitude mix exactly.
-template <int D, bool H3>
+// PREF (round 4 experiment, FACL_BWD2_PREF=1): the NEXT half unit's 16 loads are issued as soon as this half unit's dz2 / y2
+// registers are consumed (step 1), so they fly under the MFMA / layer-1 / dW2 work instead of being waited for at the top.
+template <int D, bool H3, bool PREF = false>
 __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
     const float* __restrict__ dz2f, const float* __restrict__ y2f, const float* __restrict__ x, int nunits,
     const float* __restrict__ bw2 /* (4,64): scale2, A, B, mean2 */, const float* __restrict__ W2,
@@ -138,6 +140,17 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
 
     // rev: walk the units from the LAST one down.  The pass before this one (k_sa_bwd1) wrote dz2 and read y2 front to back, so
     // the ends of both arrays are what the memory-side cache (256 MB) still holds when this kernel starts.
+    float4 zv[8], yv[8];                                    // [rt*4 + r4] of the current half unit
+    auto load_half = [&](int u, int ct) {
+        const float* zt = dz2f + (size_t)u * FACL_UNIT_ELEMS + ct * 2048;
+        const float* yt = y2f + (size_t)u * FACL_UNIT_ELEMS + ct * 2048;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            zv[i] = *reinterpret_cast<const float4*>(zt + (i * 64 + lane) * 4);
+            yv[i] = *reinterpret_cast<const float4*>(yt + (i * 64 + lane) * 4);
+        }
+    };
+    if (PREF && wave_g < nunits) load_half(rev ? nunits - 1 - wave_g : wave_g, 0);
     for (int uu = wave_g; uu < nunits; uu += nwaves) {
         const int u = rev ? nunits - 1 - uu : uu;
         {   // x of the unit -> LDS (one float4 per position)
@@ -149,14 +162,7 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
         }
 #pragma unroll 1
         for (int ct = 0; ct < 2; ++ct) {
-            const float* zt = dz2f + (size_t)u * FACL_UNIT_ELEMS + ct * 2048;
-            const float* yt = y2f + (size_t)u * FACL_UNIT_ELEMS + ct * 2048;
-            float4 zv[8], yv[8];                            // [rt*4 + r4]: all 16 loads in flight before the first use
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                zv[i] = *reinterpret_cast<const float4*>(zt + (i * 64 + lane) * 4);
-                yv[i] = *reinterpret_cast<const float4*>(yt + (i * 64 + lane) * 4);
-            }
+            if (!PREF) load_half(u, ct);                    // all 16 loads in flight before the first use
             // ---- 1. dy2 -> 16-bit planes: registers (A operand of da1) + LDS image (transposed A operand of dW2)
             bf16x8 ap[4][3];                                // [k16 block][plane]
             float uns_da = 1.f, uns_dw = 1.f;               // H3: inverse scales of this half unit's da1 / dW2 tiles
@@ -228,6 +234,10 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
                 ap[kk][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
                 ap[kk][2] = as_bf16x8(lo[0], lo[1], lo[2], lo[3]);
             }
+            }
+            if (PREF) {                                     // zv / yv are consumed: the next half unit's loads take their place
+                const int un = uu + nwaves < nunits ? (rev ? nunits - 1 - (uu + nwaves) : uu + nwaves) : u;   // last round: re-reads its own (L2 hit)
+                if (ct == 0) load_half(u, 1); else load_half(un, 0);
             }
             // ---- 2. da1[p][c1] = sum_c2 dy2[p][c2] W2[c2][c1]   (tiles: rows = positions, lane = c1)
             f32x16 da1[2];                                  // [c1 tile]
@@ -374,20 +384,18 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
 int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, int nunits, int D, const float* bw2,
                            const float* W2, const float* l1tab, double* ws, int grid, const uint32_t* a1amax, hipStream_t st) {
     const size_t lds = (1536 + 64 + B2S_WAVES * 64) * sizeof(float4) + B2S_WAVES * (size_t)B2S_IMG;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* fns[4] = {(const void*)k_sa_bwd2_sb<4, true>, (const void*)k_sa_bwd2_sb<3, true>,
-                              (const void*)k_sa_bwd2_sb<4, false>, (const void*)k_sa_bwd2_sb<3, false>};
-        for (int i = 0; i < 4; ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        attr_done = true;
-    }
+    static bool attr_done[64] = {};
+    const void* fns[6] = {(const void*)k_sa_bwd2_sb<4, true>, (const void*)k_sa_bwd2_sb<3, true>, (const void*)k_sa_bwd2_sb<4, false>,
+                          (const void*)k_sa_bwd2_sb<3, false>, (const void*)k_sa_bwd2_sb<4, true, true>, (const void*)k_sa_bwd2_sb<3, true, true>};
+    if (int rc = facl_set_dynamic_lds(attr_done, fns, 6, (int)lds)) return rc;
     static const int rev = getenv("FACL_BWD2_REV") ? atoi(getenv("FACL_BWD2_REV")) : 1;
     static const int h3 = getenv("FACL_BWD_H3") ? atoi(getenv("FACL_BWD_H3")) : 1;     // 0: bf16x6 (A/B)
     const dim3 g(grid), b(64 * B2S_WAVES);
-    if (h3) {
+    static const int pref = getenv("FACL_BWD2_PREF") ? atoi(getenv("FACL_BWD2_PREF")) : 0;
+    if (h3 && pref) {
+        if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, true, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
+        else hipLaunchKernelGGL((k_sa_bwd2_sb<3, true, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
+    } else if (h3) {
         if (D == 4) hipLaunchKernelGGL((k_sa_bwd2_sb<4, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
         else hipLaunchKernelGGL((k_sa_bwd2_sb<3, true>), g, b, lds, st, dz2f, y2f, x, nunits, bw2, W2, l1tab, ws, rev, a1amax);
     } else {

@@ -522,8 +522,10 @@ __device__ __forceinline__ unsigned pk_f16q(float x0, float x1) {
     const f32x2v v = {x0, x1};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2q));
 }
-template <int NP>
-__global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2f, int nunits,
+// WAVES / PREF: 8 waves per workgroup (two per SIMD) with the next unit's y2 tile prefetched into a second register set (206
+// registers), or -- round 4 experiment, FACL_FWD3_W12=1 -- 12 waves (three per SIMD) without the prefetch (<= 170 registers).
+template <int NP, int WAVES = 8, bool PREF = true>
+__global__ __launch_bounds__(64 * WAVES) void k_sa_fwd3_sb(const float* __restrict__ y2f, int nunits,
                                                     const float* __restrict__ sc2, const float* __restrict__ sh2,
                                                     const float* __restrict__ W3, const float* __restrict__ b3,
                                                     const float* __restrict__ sgn3, float* __restrict__ ymax,
@@ -539,11 +541,12 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
     // fp16x3 operand scales (common.h): W3 by the power of two of its own maximum -- every thread first loads the 32 weights
     // it is going to split (one pass over W3, all loads in flight), the workgroup takes the maximum, then the fragments are
     // split from registers --, a2 by the one of its bound
-    float4 wv[4][2];
+    constexpr int NIT = (2048 + 64 * WAVES - 1) / (64 * WAVES);
+    float4 wv[NIT][2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = threadIdx.x + 512 * it;
-        const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 64 * WAVES * it;
+        const int ln = i & 63, kk = (i >> 6) & 3, ct3 = (i >> 8) & 7;
         const float* wrow = W3 + (32 * ct3 + (ln & 31)) * 64 + 16 * kk + 4 * (ln >> 5);
         wv[it][0] = *reinterpret_cast<const float4*>(wrow);
         wv[it][1] = *reinterpret_cast<const float4*>(wrow + 8);
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
     if (NP == 4) {
         float m = 0.f;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < NIT; ++it)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 m = fmaxf(fmaxf(m, fmaxf(fabsf(wv[it][e].x), fabsf(wv[it][e].y))), fmaxf(fabsf(wv[it][e].z), fabsf(wv[it][e].w)));
@@ -560,15 +563,18 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if ((threadIdx.x & 63) == 0) b3s[threadIdx.x >> 6] = m;          // LDS scratch: b3s is filled further down
         __syncthreads();
-        m = fmaxf(fmaxf(fmaxf(b3s[0], b3s[1]), fmaxf(b3s[2], b3s[3])), fmaxf(fmaxf(b3s[4], b3s[5]), fmaxf(b3s[6], b3s[7])));
+        m = b3s[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) m = fmaxf(m, b3s[w]);
         __syncthreads();
         seW = __builtin_amdgcn_readfirstlane(h3_se(__float_as_uint(m)));
         seA = h3_se_of(a2amax);
     }
     const float sW3 = pow2_biased(seW), sA2 = pow2_biased(seA), UNS = h3_unscale(seA, seW);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = threadIdx.x + 512 * it;
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 64 * WAVES * it;
+        if (i >= 2048) break;
         const int ln = i & 63, kk = (i >> 6) & 3, ct3 = i >> 8;
         const int c3 = 32 * ct3 + (ln & 31);
         float4 w0 = wv[it][0], w1 = wv[it][1];
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
     __syncthreads();
 
     const int lane = lane_id(), h = lane >> 5, q = lane & 31;
-    const int wave_g = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + (threadIdx.x >> 6)), nwaves = gridDim.x * 8;   // uniform: scalar addresses
+    const int wave_g = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6)), nwaves = gridDim.x * WAVES;   // uniform: scalar addresses
 #pragma unroll
     for (int i = 0; i < 4; ++i) stat[i * 64 + lane] = make_double2(0.0, 0.0);
 
@@ -623,9 +629,10 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
 #pragma unroll
         for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
     };
-    if (wave_g < nunits) issue_loads(wave_g);
+    if (PREF && wave_g < nunits) issue_loads(wave_g);
     int nun = 0;
     for (int u = wave_g; u < nunits; u += nwaves, ++nun) {
+        if (!PREF) issue_loads(u);           // three waves per SIMD cover the latency instead of a second register set
         bf16x8 ap[2][4][3];                  // [position tile][k16 block][plane]
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(512) void k_sa_fwd3_sb(const float* __restrict__ y2
         // unconditional (the last round re-reads its own unit, an L2 hit): under `if (u + nwaves < nunits)` the register
         // allocator merged the loaded / not-loaded values with copies OUT of the freshly loaded registers, behind an
         // s_waitcnt vmcnt(8) -- every wave stalled for a full memory round trip per unit (~100 us of the kernel's 360)
-        issue_loads(u + nwaves < nunits ? u + nwaves : u);
+        if (PREF) issue_loads(u + nwaves < nunits ? u + nwaves : u);
         // One column tile (32 channels) = 8 / 12 / 24 MFMAs into two accumulators (the unit's two position tiles), then an
         // epilogue of ~130 VALU instructions on them.
         auto mma_tile = [&](int ct3, f32x16& acc0, f32x16& acc1) {
@@ -854,20 +861,26 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
     if (!y2f || !scale2 || !shift2 || !W3 || !b3 || !sgn3 || !ymax || !arg || (sums3 && !ws) || (prec == 3 && !a2amax)) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 7) / 8 : SA_GRID);
+    static const int w12 = getenv("FACL_FWD3_W12") ? atoi(getenv("FACL_FWD3_W12")) : 0;      // experiment: 12 waves, no prefetch
+    const int WV = (w12 && prec == 3) ? 12 : 8;
+    const int grid = (int)(nunits < SA_GRID * WV ? (nunits + WV - 1) / WV : SA_GRID);
     // FACL_SA_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one
     static const int env_f32 = getenv("FACL_SA_F32") ? atoi(getenv("FACL_SA_F32")) : 0;
     const int use_f32 = env_f32 && prec == 0;
     const size_t lds = use_f32 ? (4096 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 512 * sizeof(double2)
-                               : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + 8 * 256 * sizeof(double2);
+                               : (6144 + 32) * sizeof(float4) + 256 * sizeof(float) + WV * 256 * sizeof(double2);
     const void* fn = use_f32 ? (const void*)k_sa_fwd3 : prec == 1 ? (const void*)k_sa_fwd3_sb<1>
                    : prec == 2 ? (const void*)k_sa_fwd3_sb<2> : prec == 3 ? (const void*)k_sa_fwd3_sb<4> : (const void*)k_sa_fwd3_sb<3>;
-    static bool attr_done[4] = {false, false, false, false};
     if (prec < 0 || prec > 3) return FACL_E_CONFIG;
-    if (!attr_done[prec]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_done[64][5] = {};                 // per device ordinal (the attribute is per device) and kernel variant
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    const int slot = WV == 12 ? 4 : prec;
+    if (!attr_done[dev][slot]) {
+        hipError_t e = hipFuncSetAttribute(WV == 12 ? (const void*)k_sa_fwd3_sb<4, 12, false> : fn,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done[prec] = true;
+        attr_done[dev][slot] = true;
     }
     double* part = sums3 ? (double*)ws : nullptr;
     if (use_f32)
@@ -879,6 +892,9 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
     else if (prec == 2)
         hipLaunchKernelGGL((k_sa_fwd3_sb<2>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
                            ymax, arg, part, a2amax);
+    else if (prec == 3 && WV == 12)
+        hipLaunchKernelGGL((k_sa_fwd3_sb<4, 12, false>), dim3(grid), dim3(768), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
+                           ymax, arg, part, a2amax);
     else if (prec == 3)
         hipLaunchKernelGGL((k_sa_fwd3_sb<4>), dim3(grid), dim3(512), lds, st, y2f, (int)nunits, scale2, shift2, W3, b3, sgn3,
                            ymax, arg, part, a2amax);
@@ -887,7 +903,7 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
                            ymax, arg, part, a2amax);
     int rc = facl_launch_status();
     if (rc || !sums3) return rc;
-    return facl_reduce_rows(part, grid * 8, 512, sums3, st);
+    return facl_reduce_rows(part, grid * WV, 512, sums3, st);
 }
 
 extern "C" int facl_sa_fwd3(const float* y2f, int64_t nunits, const float* scale2, const float* shift2,

@@ -12,6 +12,7 @@ from . import _lib
 _FWD_H3 = __import__("os").environ.get("FACL_FWD_H3", "1") != "0"
 # eval mode through the ONE-kernel path (csrc/sa_eval.hip); FACL_EVAL_FUSED=0: the training passes with folded constants (A/B)
 _EVAL_FUSED = __import__("os").environ.get("FACL_EVAL_FUSED", "1") != "0"
+_EXTRA_LAUNCHES = int(__import__("os").environ.get("FACL_EXTRA_LAUNCHES", "0"))
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 UNIT = 64
@@ -102,6 +103,8 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
         only the unbiased running-variance factor needs the true count."""
     lib = _lib.load_library()
     _lib.require_cuda(x_rows)
+    for _ in range(_EXTRA_LAUNCHES):                 # experiment knob: what does one more tiny dependent kernel cost inside the step?
+        _bn_eval(64, p["g1"], p["be1"], p["rm1"], p["rv1"])
     rep, R = 1, 1
     if K != UNIT:
         if K > UNIT and K % UNIT == 0:

@@ -24,6 +24,10 @@ def main():
         names.append("bench_rehearse_dp")
     optin = [n for n in ("bench_optin_x3b", "bench_optin_x3") if os.path.exists(os.path.join(go, f"{tag}_{n}.json"))]
     names += optin
+    extra = [n for n in ("bench_rehearse_dp_fullgraph", "bench_extract", "bench_extract_unfused") if os.path.exists(os.path.join(go, f"{tag}_{n}.json"))]
+    names += extra
+    if os.path.exists(os.path.join(go, f"{tag}_views.json")):
+        shutil.copy(os.path.join(go, f"{tag}_views.json"), os.path.join(pr, f"{tag}_views.json"))
     for n in names:
         shutil.copy(os.path.join(go, f"{tag}_{n}.json"), os.path.join(pr, f"{tag}_{n}.json"))
     shutil.copy(os.path.join(go, f"prof_{tag}", "r_kernel_stats.csv"), os.path.join(pr, f"{tag}_default_cmd_kernel_stats.csv"))
@@ -86,6 +90,18 @@ def main():
         dp_row = (f'| `python bench.py --rehearse-dp 1` (the DATA-PARALLEL code path on one GPU: every collective of the N > 1 step executes '
                   f'on a 1-rank RCCL group, the step replays as graph segments cut at the collectives; not a scaling number) | '
                   f'{L["bench_rehearse_dp"]["ms_per_step"]} | {L["bench_rehearse_dp"]["value"]} | `{tag}_bench_rehearse_dp.json` |\n')
+    if "bench_rehearse_dp_fullgraph" in L:
+        dp_row += (f'| `FACL_DP_GRAPH=full python bench.py --rehearse-dp 1` (OPT-IN: the same data-parallel step with its collectives captured INSIDE '
+                   f'one graph -- no cuts; 1-rank RCCL rehearsal, never run with N > 1) | {L["bench_rehearse_dp_fullgraph"]["ms_per_step"]} | '
+                   f'{L["bench_rehearse_dp_fullgraph"]["value"]} | `{tag}_bench_rehearse_dp_fullgraph.json` |\n')
+    if "bench_extract" in L:
+        e = L["bench_extract"]
+        dp_row += (f'| `python bench.py --config extract` (SURVEY 8 f-1: feature extraction, eval-mode encoder, net3DV_1 as ONE kernel; own metric '
+                   f'string) | {e["ms_per_step"]} | {e["value"]} | `{tag}_bench_extract.json` (k_sa_eval {e["roofline"]["ms_per_launch"]} ms = '
+                   f'{e["roofline"]["frac"]} of the fp16 MFMA peak; cpu_baseline {e.get("cpu_baseline", {}).get("value", "-")} clips/s) |\n')
+    if "bench_extract_unfused" in L:
+        dp_row += (f'| `FACL_EVAL_FUSED=0 python bench.py --config extract` (the rounds 1-3 eval path: training kernels with folded constants) | '
+                   f'{L["bench_extract_unfused"]["ms_per_step"]} | {L["bench_extract_unfused"]["value"]} | `{tag}_bench_extract_unfused.json` |\n')
     optin_rows = "".join(
         f'| `python bench.py --precision {n.split("_")[-1]}` (OPT-IN arithmetic, not the headline: DESIGN 3.0) | {L[n]["ms_per_step"]} | '
         f'{L[n]["value"]} | `{tag}_{n}.json` |\n' for n in optin)

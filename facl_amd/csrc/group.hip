@@ -250,4 +250,4 @@ extern "C" int facl_group_clips(const float* clips, int B, int G, int N, int D, 
     return group_entry(clips, B * G, N, D, S, K, r2, idx, xt, yt, B, stream);
 }
 
-extern "C" int facl_version(void) { return (1 << 16) | 0; }
+extern "C" int facl_version(void) { return (1 << 16) | 4; }   // minor = the round whose signatures the header describes

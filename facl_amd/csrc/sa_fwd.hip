@@ -523,7 +523,7 @@ __device__ __forceinline__ unsigned pk_f16q(float x0, float x1) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2q));
 }
 // WAVES / PREF: 8 waves per workgroup (two per SIMD) with the next unit's y2 tile prefetched into a second register set (206
-// registers), or -- round 4 experiment, FACL_FWD3_W12=1 -- 12 waves (three per SIMD) without the prefetch (<= 170 registers).
+// registers), or -- the fp16x3 default since round 4 -- 12 waves (three per SIMD) without the prefetch (160 registers).
 template <int NP, int WAVES = 8, bool PREF = true>
 __global__ __launch_bounds__(64 * WAVES) void k_sa_fwd3_sb(const float* __restrict__ y2f, int nunits,
                                                     const float* __restrict__ sc2, const float* __restrict__ sh2,
@@ -861,7 +861,9 @@ static int sa_fwd3_p(const float* y2f, int64_t nunits, const float* scale2, cons
     if (!y2f || !scale2 || !shift2 || !W3 || !b3 || !sgn3 || !ymax || !arg || (sums3 && !ws) || (prec == 3 && !a2amax)) return FACL_E_NULL;
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    static const int w12 = getenv("FACL_FWD3_W12") ? atoi(getenv("FACL_FWD3_W12")) : 0;      // experiment: 12 waves, no prefetch
+    // 12 waves per workgroup (three per SIMD, 160 registers, no register prefetch of the next y2 tile) since round 4: 0.350 vs
+    // 0.359 ms at the headline shape, three alternating same-box runs (gpurun_out: FACL_FWD3_W12=0 restores 8 waves + prefetch)
+    static const int w12 = getenv("FACL_FWD3_W12") ? atoi(getenv("FACL_FWD3_W12")) : 1;
     const int WV = (w12 && prec == 3) ? 12 : 8;
     const int grid = (int)(nunits < SA_GRID * WV ? (nunits + WV - 1) / WV : SA_GRID);
     // FACL_SA_F32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one

@@ -107,6 +107,45 @@ def test_sa_eval_one_kernel_vs_training_kernels_and_fp64(D, neg, K):
     assert torch.equal(bad[keep], fused[keep])
 
 
+@pytest.mark.parametrize("scale_x,gscale", [(1.0, 1.0), (40.0, 1.0), (1.0, 2.0 ** -11), (1e-3, 300.0)])
+def test_fp16x3_activation_bounds_are_rigorous_and_scale_free(scale_x, gscale):
+    """The device-side operand maxima of the fp16x3 passes (csrc/common.h): in training the bounds facl_bn_finalize writes
+    (Samuelson: |gamma| sqrt(n-1) sigma invstd + |beta|) must lie ABOVE the true activation maxima -- never an fp16 overflow --
+    and within 2^12 of them; max(pooled) is exact.  Inputs scaled by 40 or 1e-3 and BatchNorm weights of 2^-11 or 300 (outside
+    the rounds 1-3 range contract |a| < 4094, |w| < 255 / the 2^-11 subnormal edge) leave the result at 2e-5 of fp64."""
+    from facl_amd import sa_mlp, utils_my
+    from oracle.weights import formula_state_dict
+    torch.manual_seed(3)
+    D, M, N, S, K = 4, 8, 512, 64, 64
+    pts = (torch.rand(M, N, D) - 0.5) * scale_x
+    xt, _ = utils_my.knn_radius_group(pts.to(DEV), S, K, 0.1 * scale_x * scale_x)
+    sd = dict(formula_state_dict(D))
+    for li in (1, 4, 7):                                               # BatchNorm weights / biases of the three layers
+        sd[f"net3DV_1.{li}.weight"] = np.asarray(sd[f"net3DV_1.{li}.weight"]) * np.float32(gscale)
+        sd[f"net3DV_1.{li}.bias"] = np.asarray(sd[f"net3DV_1.{li}.bias"]) * np.float32(gscale)
+    p = _params(sd, DEV)
+    x_rows = xt.permute(0, 2, 3, 1).reshape(-1, D).contiguous()
+    pooled, ctx = sa_mlp.sa_mlp_forward(x_rows, p, True, update_running=False)
+    am = ctx["amax"].view(torch.float32)[:, ::32]                     # the 64 slots of each buffer (the words between them are unused)
+    bound_a1, bound_a2, max_pooled = float(am[1].max()), float(am[2].max()), float(am[3].max())
+    # fp64 truth of the activations
+    q = {k: p[k].double() for k in sa_mlp._PARAM_ORDER}
+    h = x_rows.double()
+    acts = []
+    for Wk, bk, gk, bek in (("W1", "b1", "g1", "be1"), ("W2", "b2", "g2", "be2"), ("W3", "b3", "g3", "be3")):
+        y = h @ q[Wk].reshape(q[Wk].shape[0], -1).t() + q[bk]
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * q[gk] + q[bek])
+        acts.append(h)
+    ref = acts[2].view(M * S, K, 256).max(dim=1).values
+    t1, t2 = float(acts[0].max()), float(acts[1].max())
+    print(f"a1: bound {bound_a1:.3e} / true max {t1:.3e};  a2: bound {bound_a2:.3e} / true max {t2:.3e};  pooled max {max_pooled:.3e} / {float(ref.max()):.3e}")
+    assert t1 <= bound_a1 <= 4096 * t1 and t2 <= bound_a2 <= 4096 * t2
+    assert abs(max_pooled - float(ref.max())) <= 1e-5 * float(ref.max())
+    assert torch.isfinite(pooled).all()
+    assert max_rel_rows(pooled.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+
+
 def test_sa_forward_c1_golden():
     """Stage pin against the reference's own net3DV_1 output (forward hook tap in make_goldens)."""
     from facl_amd import sa_mlp, utils_my

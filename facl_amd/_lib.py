@@ -100,6 +100,14 @@ SIGNATURES = {
     "facl_viewmax_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "facl_viewmax_bwd_add": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "facl_sa_bwd_final": [c_p] * 13 + [c_i, c_d] + [c_p] * 9 + [c_p],
+    "facl_viewmax_stack": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "facl_fc_bn_stats": [c_p, c_l, c_l, c_i, c_p, c_p, c_p],
+    "facl_fc_bn_apply": [c_p, c_l, c_l, c_i, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p],
+    "facl_fc_bn_bwd_stats": [c_p, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_fc_bn_bwd_apply": [c_p, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_d, c_d, c_p, c_p, c_p, c_p, c_p],
+    "facl_col_sums": [c_p, c_l, c_i, c_p, c_p],
+    "facl_contrast_pair_sum": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
+    "facl_gemm_wgrad_acc": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_p],
 }
 RESTYPE_I64 = {"facl_ws_bytes", "facl_gemm_rs_planes_bytes"}
 

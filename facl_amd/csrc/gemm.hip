@@ -44,6 +44,7 @@ struct GemmArgs {
     int prec;                          // 0: fp32 result (bf16x6 or fp32 MFMA), 1: fp16 inputs, one MFMA product, fp32 accumulate
     const unsigned* amax;              // NP = 4 (fp16x3 weight gradient): bits of max|A| in hashed slots (common.h), A = dy
     const unsigned* amax_b;            // NP = 4: bound of max|B| (the activation operand), same format
+    int accum;                         // 1: C += result (gemm_epilogue, vectorised stores only: facl_gemm_wgrad_acc)
 };
 
 template <int LAY, int T>
@@ -184,13 +185,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
         const int il = (64 / LPR) * t + lane / LPR, c4 = (lane % LPR) * 4;
         const int i = i0 + WR * wr + il;
         if (i >= g.MI) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
-        if (vec_ok) *reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]) = v;
-        else {
+        float4 v = *reinterpret_cast<const float4*>(&stg[il * SP + c4]);
+        if (vec_ok) {
+            float4* dst = reinterpret_cast<float4*>(&Cz[(size_t)i * g.ldc + jw + c4]);
+            if (g.accum) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *dst = v;
+        } else {
             const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k];
+                if (jw + c4 + k < g.NJ) Cz[(size_t)i * g.ldc + jw + c4 + k] = e[k] + (g.accum ? Cz[(size_t)i * g.ldc + jw + c4 + k] : 0.f);
         }
     }
 }
@@ -1168,4 +1172,18 @@ extern "C" int facl_gemm_dgrad_x3(const float* dy, int64_t M, int N, const float
 extern "C" int facl_gemm_wgrad_x3(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                                   float* slices, int nz, void* stream) {
     return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 2);
+}
+
+// ---- round 5 (prec: 0 = fp32-grade, 1 = fp16 inputs, 2 = bf16x3) -----------------------------------------------------------------
+// dW (N,K) += dy^T a: the weight-gradient GEMM accumulating INTO its output -- the second gradient path of the loss's keys
+// (utils_my._ContrastivePair.backward: d x += dsim^T @ stacked) without a separate add launch.  Few rows only (the
+// workgroup-level split-K kernel writes its tile once): FACL_E_CONFIG otherwise, the caller then adds itself.
+extern "C" int facl_gemm_wgrad_acc(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW, int prec,
+                                   void* stream) {
+    if (!dy || !a || !dW) return FACL_E_NULL;
+    if (M < 1 || M > 8192 || N < 4 || (N & 3) || K < 4 || (K & 3) || prec < 0 || prec > 2) return FACL_E_SHAPE;
+    GemmArgs g1{dy, N, a, lda, dW, K, N, K, (int)M, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (int)M, nullptr, nullptr, nullptr, prec};
+    g1.accum = 1;
+    if (!sbk_fits(g1, 1)) return FACL_E_CONFIG;
+    return launch<IC, IC, false>(g1, 1, (hipStream_t)stream, nullptr);
 }

@@ -364,6 +364,42 @@ extern "C" int facl_contrast_pair(const float* sim, int G, int B, int Bk, int J,
     return facl_reduce_rows((const double*)ws, B, 2, losses, st);
 }
 
+// facl_contrast_pair whose final reduction also writes the fp32 values the training loop works with: losses32 =
+// [loss_c, loss_circle, loss_circle + loss_c] (the sum in fp32, exactly the reference's `loss = loss_circle + loss_c` on the two
+// fp32 losses, cn3d_train_motion_GL.py:329) -- one single-workgroup launch instead of a reduction, a dtype cast and an add.
+namespace {
+__global__ __launch_bounds__(64) void k_loss_finish(const double* __restrict__ part, int B, double* __restrict__ losses,
+                                                    float* __restrict__ losses32) {
+    double c = 0, o = 0;
+    for (int n = threadIdx.x; n < B; n += 64) { c += part[2 * n]; o += part[2 * n + 1]; }
+    c = wave_sum_f64(c);
+    o = wave_sum_f64(o);
+    if (threadIdx.x == 0) {
+        losses[0] = c; losses[1] = o;
+        const float fc = (float)c, fo = (float)o;
+        losses32[0] = fc; losses32[1] = fo; losses32[2] = fo + fc;
+    }
+}
+}  // namespace
+
+extern "C" int facl_contrast_pair_sum(const float* sim, int G, int B, int Bk, int J, const int64_t* order, int clip_offset,
+                                      float* dsim, double* losses, float* losses32, void* ws, void* stream) {
+    if (!sim || !order || !dsim || !losses || !losses32 || !ws) return FACL_E_NULL;
+    if (G < 2 || B < 1 || Bk < 1 || J != G * Bk) return FACL_E_SHAPE;
+    if (clip_offset < 0 || clip_offset + B > Bk) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024)
+        hipLaunchKernelGGL(k_contrast_pair_reg, dim3(2 * B), dim3(1024), 0, st, sim, G, B, Bk, J, (const long long*)order,
+                           clip_offset, dsim, (double*)ws);
+    else
+        hipLaunchKernelGGL(k_contrast_pair, dim3(2 * B), dim3(256), 0, st, sim, G, B, Bk, J, (const long long*)order,
+                           clip_offset, dsim, (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, st, (const double*)ws, B, losses, losses32);
+    return facl_launch_status();
+}
+
 extern "C" int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J, const float* g1, const float* g2,
                                 void* stream) {
     if (!src || !dst || !g1 || !g2) return FACL_E_NULL;

@@ -309,6 +309,9 @@ class _Linear(torch.autograd.Function):
         return gemm_dgrad(dy, W, prec=bp), gemm_wgrad(dy, h, prec=bp), dy.sum(0)
 
 
+_FC_FUSED = __import__("os").environ.get("FACL_FC_FUSED", "1") != "0"          # A/B switch: 0 = the single-segment kernels of rounds 2-4
+
+
 class _FCHead(torch.autograd.Function):
     """gobaol_max_pool (cn3d_model_conbag.py:225-226) + netR_FC (Linear -> BatchNorm1d -> ReLU -> Linear, :201-207) applied
     to the per-view rows AND to the per-clip rows (:228-229) in one pass.
@@ -319,7 +322,13 @@ class _FCHead(torch.autograd.Function):
     reference's two separate batch statistics and its two sequential running-statistics updates, segment by segment.
     Keeping the stacked tensor whole lets the loss run ONE similarity GEMM on it (utils_my._ContrastivePair) and spares
     the cat / split launches of both directions; in the backward the view-max gradient is scattered straight into the
-    rows of dL/dx_pre (no (G*B, C) zero tensor, no autograd accumulation kernel)."""
+    rows of dL/dx_pre (no (G*B, C) zero tensor, no autograd accumulation kernel).
+
+    Round 5: this block is ~50 launches of a few microseconds each around nine ~20 us GEMMs, i.e. launch latency.  The
+    two-segment BatchNorm is three launches per direction (csrc/fchead.hip: fp64 slice statistics
+    -> both finalisations -> one apply; backward: slice sums -> constants + parameter gradients of both segments
+    -> one apply) instead of nine / eleven, the view maximum fills the stacked input in the launch that reads it, and the
+    bias gradient is one column-sum launch."""
 
     @staticmethod
     def forward(ctx, x_pre, G, W1, b1, gamma, beta, bn, W2, b2, training, reduce_fn):
@@ -331,38 +340,67 @@ class _FCHead(torch.autograd.Function):
         M, Cin = x_pre.shape
         B = M // G
         h = _lib.empty((M + B, Cin), dtype=torch.float32, device=x_pre.device)
-        h[:M].copy_(x_pre)
         arg = _lib.empty((B, Cin), dtype=torch.int32, device=x_pre.device)
-        _lib.check(lib.facl_viewmax_fwd(_lib.ptr(x_pre), G, B, Cin, h[M:].data_ptr(), _lib.ptr(arg), _lib.stream()), "facl_viewmax_fwd")
+        _lib.check(lib.facl_viewmax_stack(_lib.ptr(x_pre), G, B, Cin, _lib.ptr(h), _lib.ptr(arg), _lib.stream()), "facl_viewmax_stack")
         _lib.tap("view_arg", arg)
         W1, W2 = W1.contiguous(), W2.contiguous()
-        y, _ = gemm_fwd(h, W1, b1, prec=ctx.prec)
-        R, C = y.shape
+        R, C = M + B, W1.shape[0]
         segs = ((0, M), (M, R))
-        a = _lib.empty_like(y)
-        bncs, counts = [], []
-        if training:
-            # both segments' statistics first, ONE SyncBN all-reduce for the pair, then the two finalisations in the
-            # reference's order (view rows :228, clip rows :229: the running statistics are updated twice)
-            sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
-            for i, (r0, r1) in enumerate(segs):
-                _lib.check(lib.facl_rows_stats(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()),
-                           "facl_rows_stats")
-            world = 1
+        fused = _FC_FUSED and training and M % 32 == 0 and C % 4 == 0
+        ctx.fused = fused
+        if fused:
+            f32 = dict(dtype=torch.float32, device=x_pre.device)
+            world = 1 if reduce_fn is None else reduce_fn.world_size
+            counts = [float(M) * world, float(B) * world]
+            sums2 = part = None
+            na = nb = 0
+            # (statistics out of the first GEMM's epilogue -- fp32 sums over 32 rows, tried -- save one more
+            # launch but lose the clip segment's variance: B = 4..32 rows, var = E[y^2] - mean^2 of fp32-rounded sums put
+            # x_global 1.4e-4 from fp64 on the C1 golden (gpurun_out/r5a_tests.log).  The slice statistics stay fp64.)
+            y = gemm_fwd(h, W1, b1, prec=ctx.prec)[0]
             if reduce_fn is not None:
-                reduce_fn(sums2)
-                world = reduce_fn.world_size
-        for i, (r0, r1) in enumerate(segs):
-            if training:
-                count = float(r1 - r0) * world
-                bnc = _bn_finalize(sums2[i], C, count, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var)
-                bn.count_batch()
+                sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
+            _lib.check(lib.facl_fc_bn_stats(_lib.ptr(y), M, R, C, _lib.ptr(sums2), _lib.ptr(ws), _lib.stream()), "facl_fc_bn_stats")
+            if reduce_fn is not None:
+                reduce_fn(sums2)                                 # ONE SyncBN all-reduce for the pair
             else:
-                bnc, count = _forward_bn_consts(y[r0:r1], bn, False, None, ws)
-            _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
-                                             _lib.ptr(a[r0:r1]), _lib.stream()), "facl_rows_bn_relu")
-            bncs.append(bnc)
-            counts.append(count)
+                part, na, nb = ws, M // 32, (B + 31) // 32
+            a = _lib.empty_like(y)
+            bnc2 = _lib.empty((2, 5, C), **f32)
+            _lib.check(lib.facl_fc_bn_apply(_lib.ptr(y), M, R, C, _lib.ptr(sums2), _lib.ptr(part), na, nb, counts[0], counts[1],
+                                            _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()), BN_EPS, BN_MOMENTUM,
+                                            _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(bnc2), _lib.ptr(a),
+                                            _lib.stream()), "facl_fc_bn_apply")
+            bn.count_batch()
+            bn.count_batch()
+            bncs = [bnc2[0], bnc2[1]]
+            ctx.bnc2 = bnc2
+        else:
+            y, _ = gemm_fwd(h, W1, b1, prec=ctx.prec)
+            a = _lib.empty_like(y)
+            bncs, counts = [], []
+            if training:
+                # both segments' statistics first, ONE SyncBN all-reduce for the pair, then the two finalisations in the
+                # reference's order (view rows :228, clip rows :229: the running statistics are updated twice)
+                sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
+                for i, (r0, r1) in enumerate(segs):
+                    _lib.check(lib.facl_rows_stats(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()),
+                               "facl_rows_stats")
+                world = 1
+                if reduce_fn is not None:
+                    reduce_fn(sums2)
+                    world = reduce_fn.world_size
+            for i, (r0, r1) in enumerate(segs):
+                if training:
+                    count = float(r1 - r0) * world
+                    bnc = _bn_finalize(sums2[i], C, count, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var)
+                    bn.count_batch()
+                else:
+                    bnc, count = _forward_bn_consts(y[r0:r1], bn, False, None, ws)
+                _lib.check(lib.facl_rows_bn_relu(_lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc[2]), _lib.ptr(bnc[3]),
+                                                 _lib.ptr(a[r0:r1]), _lib.stream()), "facl_rows_bn_relu")
+                bncs.append(bnc)
+                counts.append(count)
         _lib.tap_relu("relu_fc", a=a)
         out, _ = gemm_fwd(a, W2, b2, prec=ctx.prec)
         ctx.save_for_backward(h, W1, y, a, W2, arg, *bncs)
@@ -378,28 +416,46 @@ class _FCHead(torch.autograd.Function):
         h, W1, y, a, W2, arg, bnc_a, bnc_b = ctx.saved_tensors
         ws = _Workspace.get(y.device)
         R, C = y.shape
-        dout = dout.contiguous()
-        dW2 = gemm_wgrad(dout, a, prec=bp)
-        db2 = dout.sum(0)
-        dact = gemm_dgrad(dout, W2, prec=bp)
-        dy = _lib.empty_like(y)
-        f32 = dict(dtype=torch.float32, device=y.device)
-        sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
-        for i, ((r0, r1), bnc) in enumerate(zip(ctx.segs, (bnc_a, bnc_b))):
-            _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
-                                               _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()), "facl_rows_bwd_stats")
-        sums2_g = ctx.reduce_fn(sums2.clone()) if ctx.reduce_fn is not None else sums2       # one all-reduce for the pair
-        dbe, dga, kk = _lib.empty((2, C), **f32), _lib.empty((2, C), **f32), _lib.empty((2, 2, C), **f32)
-        for i, ((r0, r1), bnc, count) in enumerate(zip(ctx.segs, (bnc_a, bnc_b), ctx.counts)):
-            _lib.check(lib.facl_bn_bwd_consts(_lib.ptr(sums2[i]), _lib.ptr(sums2_g[i]), C, float(count), _lib.ptr(dbe[i]),
-                                              _lib.ptr(dga[i]), _lib.ptr(kk[i]), _lib.stream()), "facl_bn_bwd_consts")
-            _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
-                                               _lib.ptr(kk[i]), _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
-        dgamma, dbeta = dga[0] + dga[1], dbe[0] + dbe[1]
-        dW1 = gemm_wgrad(dy, h, prec=bp)
-        dh = gemm_dgrad(dy, W1, prec=bp)
         M = ctx.segs[0][1]
         B = R - M
+        dout = dout.contiguous()
+        f32 = dict(dtype=torch.float32, device=y.device)
+        dW2 = gemm_wgrad(dout, a, prec=bp)
+        if dout.shape[1] % 4 == 0:
+            db2 = _lib.empty(dout.shape[1], **f32)
+            _lib.check(lib.facl_col_sums(_lib.ptr(dout), R, dout.shape[1], _lib.ptr(db2), _lib.stream()), "facl_col_sums")
+        else:
+            db2 = dout.sum(0)
+        dact = gemm_dgrad(dout, W2, prec=bp)
+        dy = _lib.empty_like(y)
+        if ctx.fused:
+            bnc2 = ctx.bnc2
+            sums2 = sums2_g = None
+            if ctx.reduce_fn is not None:
+                sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
+            _lib.check(lib.facl_fc_bn_bwd_stats(_lib.ptr(dact), _lib.ptr(y), M, R, C, _lib.ptr(bnc2), _lib.ptr(sums2), _lib.ptr(ws),
+                                                _lib.stream()), "facl_fc_bn_bwd_stats")
+            if ctx.reduce_fn is not None:
+                sums2_g = ctx.reduce_fn(sums2)                   # the local slice sums stay in the workspace
+            dgamma, dbeta, kk2 = _lib.empty(C, **f32), _lib.empty(C, **f32), _lib.empty((2, 2, C), **f32)
+            _lib.check(lib.facl_fc_bn_bwd_apply(_lib.ptr(dact), _lib.ptr(y), M, R, C, _lib.ptr(bnc2), _lib.ptr(sums2_g), _lib.ptr(ws),
+                                                ctx.counts[0], ctx.counts[1], _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(kk2),
+                                                _lib.ptr(dy), _lib.stream()), "facl_fc_bn_bwd_apply")
+        else:
+            sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)
+            for i, ((r0, r1), bnc) in enumerate(zip(ctx.segs, (bnc_a, bnc_b))):
+                _lib.check(lib.facl_rows_bwd_stats(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
+                                                   _lib.ptr(sums2[i]), _lib.ptr(ws), _lib.stream()), "facl_rows_bwd_stats")
+            sums2_g = ctx.reduce_fn(sums2.clone()) if ctx.reduce_fn is not None else sums2       # one all-reduce for the pair
+            dbe, dga, kk = _lib.empty((2, C), **f32), _lib.empty((2, C), **f32), _lib.empty((2, 2, C), **f32)
+            for i, ((r0, r1), bnc, count) in enumerate(zip(ctx.segs, (bnc_a, bnc_b), ctx.counts)):
+                _lib.check(lib.facl_bn_bwd_consts(_lib.ptr(sums2[i]), _lib.ptr(sums2_g[i]), C, float(count), _lib.ptr(dbe[i]),
+                                                  _lib.ptr(dga[i]), _lib.ptr(kk[i]), _lib.stream()), "facl_bn_bwd_consts")
+                _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
+                                                   _lib.ptr(kk[i]), _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
+            dgamma, dbeta = dga[0] + dga[1], dbe[0] + dbe[1]
+        dW1 = gemm_wgrad(dy, h, prec=bp)
+        dh = gemm_dgrad(dy, W1, prec=bp)
         # dL/dx_pre = dh[:M] + (dh[M:] routed to the winning view's row of each (clip, channel))
         _lib.check(lib.facl_viewmax_bwd_add(dh[M:].data_ptr(), _lib.ptr(arg), ctx.G, B, dh.shape[1], _lib.ptr(dh), _lib.stream()),
                    "facl_viewmax_bwd_add")

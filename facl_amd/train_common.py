@@ -122,6 +122,7 @@ class ContrastiveStep:
         self.epoch = 0
         self.r2 = group_radius
         self.fps_reorder = fps_reorder
+        self._one = None
         self.rank = torch.distributed.get_rank() if fdist.is_distributed() else 0
         self.grad_sync = fdist.GradSync(list(netR.named_parameters())) if fdist.is_distributed() else None
 
@@ -178,9 +179,9 @@ class ContrastiveStep:
         # global (:265-287) + circle (:290-316) losses: similarity GEMMs + one HIP kernel each (csrc/loss.hip)
         from .tail import precision as _precision
         with _precision(getattr(netR, "precision", "f32")):    # the similarity GEMMs follow the model's arithmetic
-            loss_c, loss_circle = contrastive_losses_stacked(G, netR._stacked, order, x_keys=None if x_keys is x else x_keys,
-                                                             clip_offset=off)
-        loss = loss_circle + loss_c                                                # :329 (swa, CLD terms are 0 ...)
+            loss_c, loss_circle, loss = contrastive_losses_stacked(G, netR._stacked, order, x_keys=None if x_keys is x else x_keys,
+                                                                   clip_offset=off, with_sum=True)
+        # loss = loss_circle + loss_c (:329; swa, CLD terms are 0 ...): the fp32 sum comes out of the loss launch itself
         if self.swa_if:                                                            # ... unless switched on: :239-263
             from . import swav_cld
             if self.swav_state is None:
@@ -191,7 +192,9 @@ class ContrastiveStep:
             from . import swav_cld
             loss = loss + swav_cld.cld_loss(x_nor, B, G)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), dtype=torch.float32, device=loss.device)    # the seed of backward(): no fill launch per step
+        loss.backward(self._one)
         if self.grad_sync is not None:
             self.grad_sync.finish()                                                # tail bucket overlapped with the SA backward
         self.optimizer.step()

@@ -234,25 +234,53 @@ class _ContrastivePair(torch.autograd.Function):
         sim = _tail.gemm_fwd(stacked, keys, None, prec=ctx.prec)[0] if ctx.mfma else stacked @ keys.t()     # ((G+1)B, J)  :71 and :103
         dsim = _lib.empty_like(sim)
         out = _lib.empty(2, dtype=torch.float64, device=dev)
-        _lib.check(lib.facl_contrast_pair(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), clip_offset, _lib.ptr(dsim),
-                                          _lib.ptr(out), _lib.ptr(ws), _lib.stream()), "facl_contrast_pair")
+        # [loss_c, loss_circle, loss_circle + loss_c] in fp32 from the loss launch's own finishing kernel (no cast / add launches)
+        out32 = _lib.empty(3, dtype=torch.float32, device=dev)
+        _lib.check(lib.facl_contrast_pair_sum(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), clip_offset, _lib.ptr(dsim),
+                                              _lib.ptr(out), _lib.ptr(out32), _lib.ptr(ws), _lib.stream()), "facl_contrast_pair_sum")
         ctx.save_for_backward(stacked, keys, dsim)
         ctx.GB = G * B
-        out32 = out.float()
-        return out32[0], out32[1]
+        ctx.set_materialize_grads(False)           # an unused loss output arrives as None, not as a freshly filled zero tensor
+        return out32[0], out32[1], out32[2]
 
     @staticmethod
-    def backward(ctx, g_c, g_o):
+    def backward(ctx, g_c, g_o, g_s):
         from . import tail as _tail
         bp = _tail.backward_precision(ctx.prec)
         stacked, keys, dsim = ctx.saved_tensors
+        # upstream gradients of (loss_c, loss_circle, their sum): the training step only uses the sum (no launch here); any
+        # other combination is tensor algebra on device scalars
+        def tot(g):
+            if g is None:
+                return g_s
+            g = g.contiguous().float()
+            return g if g_s is None else g + g_s.float()
+        g_c, g_o = tot(g_c), tot(g_o)
+        if g_c is None and g_o is None:
+            return None, None, None, None, None
+        zero = None
+        if g_c is None or g_o is None:
+            zero = torch.zeros((), dtype=torch.float32, device=dsim.device)
+        g_c = zero if g_c is None else g_c.contiguous().float()
+        g_o = zero if g_o is None else g_o.contiguous().float()
         # rows [0, G*B) carry the circle loss, rows [G*B, (G+1)*B) the global loss: one scaling launch for both
         lib = _lib.load_library()
         ds = _lib.empty_like(dsim)
         R, J = dsim.shape
-        _lib.check(lib.facl_scale_rows2(_lib.ptr(dsim), _lib.ptr(ds), ctx.GB, R, J, _lib.ptr(g_o.contiguous().float()),
-                                        _lib.ptr(g_c.contiguous().float()), _lib.stream()), "facl_scale_rows2")
+        _lib.check(lib.facl_scale_rows2(_lib.ptr(dsim), _lib.ptr(ds), ctx.GB, R, J, _lib.ptr(g_o), _lib.ptr(g_c), _lib.stream()),
+                   "facl_scale_rows2")
         d_stacked = _tail.gemm_dgrad(ds, keys, prec=bp) if ctx.mfma else ds @ keys
+        if ctx.own_keys and ctx.mfma:
+            # d keys = dsim^T @ stacked accumulated straight into the view rows of d stacked (the keys ARE those rows)
+            M_, N_, K_ = ds.shape[0], ds.shape[1], stacked.shape[1]
+            pc = {"f32": 0, "x3b": 0, "f16": 1, "x3": 2}[bp]
+            with _lib.timed("facl_gemm_wgrad %dx%dx%d%s" % (M_, N_, K_, _tail._LABEL[bp])):
+                rc = lib.facl_gemm_wgrad_acc(_lib.ptr(ds), _lib.ptr(stacked), M_, N_, K_, stacked.stride(0), _lib.ptr(d_stacked), pc,
+                                             _lib.stream())
+            if rc == 0:
+                return d_stacked, None, None, None, None
+            if rc != -4:
+                _lib.check(rc, "facl_gemm_wgrad_acc")
         d_keys = _tail.gemm_wgrad(ds, stacked, prec=bp) if ctx.mfma else ds.t() @ stacked
         if ctx.own_keys:
             d_stacked[:ctx.GB] += d_keys
@@ -269,13 +297,15 @@ def _check_order(order, G):
         raise ValueError("order must be a permutation of range(%d), got %r" % (G, o.tolist()))
 
 
-def contrastive_losses_stacked(num_crop, stacked, order, x_keys=None, clip_offset=0):
-    """(loss_c, loss_circle) from the model's stacked output [x ; x_global] (facl_amd.cn3d_model_conbag: ``_stacked``)."""
+def contrastive_losses_stacked(num_crop, stacked, order, x_keys=None, clip_offset=0, with_sum=False):
+    """(loss_c, loss_circle) from the model's stacked output [x ; x_global] (facl_amd.cn3d_model_conbag: ``_stacked``);
+    with_sum: also `loss_circle + loss_c` (fp32, cn3d_train_motion_GL.py:329) as a third output of the same launch."""
     G = num_crop
     if not (torch.is_tensor(order) and order.device == stacked.device and order.dtype == torch.long):
         _check_order(order, G)
         order = torch.as_tensor(order, device=stacked.device, dtype=torch.long)
-    return _ContrastivePair.apply(stacked, x_keys, order.contiguous(), G, clip_offset)
+    out = _ContrastivePair.apply(stacked, x_keys, order.contiguous(), G, clip_offset)
+    return out if with_sum else out[:2]
 
 
 def contrastive_losses(num_crop, x_global, x, order, x_keys=None, clip_offset=0):

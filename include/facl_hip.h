@@ -216,6 +216,32 @@ int facl_viewmax_bwd(const float* dout, const int32_t* arg, int G, int B, int C,
 /* the same routing ADDED into dx (G*B,C), whose rows already hold the other gradient path of x_pre (each (clip, channel)
  * touches exactly one element: no atomics) */
 int facl_viewmax_bwd_add(const float* dout, const int32_t* arg, int G, int B, int C, float* dx, void* stream);
+/* gobaol_max_pool straight into netR_FC's stacked input (cn3d_model_conbag.py:225-229): h (G*B + B, C) = [x ; max over the G views
+ * of x], arg (B,C) = the first view that attains the maximum -- facl_viewmax_fwd plus the copy of the rows it reads anyway. */
+int facl_viewmax_stack(const float* x, int G, int B, int C, float* h, int32_t* arg, void* stream);
+
+/* ---- netR_FC's BatchNorm1d + ReLU over the STACKED rows (cn3d_model_conbag.py:203-204 called at :228 on the G*B view rows and
+ * at :229 on the B clip rows): y (R,C), segment a = rows [0,M), segment b = rows [M,R); two batch statistics, the running
+ * buffers updated twice (a first), one set of kernels (csrc/fchead.hip).  M % 32 == 0 (else FACL_E_CONFIG: use the
+ * single-segment entries).  Statistics are kept as 32-row SLICE sums that the consumer adds itself (no reduction launch):
+ *   facl_fc_bn_stats      slice (sum, sumsq) of y into `ws`; with sums2 (2,C,2) also the segment totals (SyncBN all-reduce).
+ *   facl_fc_bn_apply      bnc2 (2,5,C) = (mean, invstd, scale, shift, sign) per segment from `sums2` (totals) or from `part`
+ *                         (nslices_a + nslices_b slice rows of (C,2) doubles: `ws` after facl_fc_bn_stats);
+ *                         running statistics (momentum, unbiased variance) for a then b; a_out = relu(bn(y)).
+ *   facl_fc_bn_bwd_stats  slice sums of dz = dact*[z>0] and dz*yhat into `ws` (+ totals into sums2).
+ *   facl_fc_bn_bwd_apply  kk2 (2,2,C), dy = scale (dz - k1 - yhat k2) with k = (all-reduced sums2_g, or the local slice sums
+ *                         in `ws`) / count; dgamma / dbeta (C) = this rank's sums of both segments (fp32 add of the two). */
+int facl_fc_bn_stats(const float* y, int64_t M, int64_t R, int C, double* sums2, void* ws, void* stream);
+int facl_fc_bn_apply(const float* y, int64_t M, int64_t R, int C, const double* sums2, const double* part, int nslices_a,
+                     int nslices_b, double count_a, double count_b, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* bnc2, float* a_out, void* stream);
+int facl_fc_bn_bwd_stats(const float* dact, const float* y, int64_t M, int64_t R, int C, const float* bnc2, double* sums2,
+                         void* ws, void* stream);
+int facl_fc_bn_bwd_apply(const float* dact, const float* y, int64_t M, int64_t R, int C, const float* bnc2,
+                         const double* sums2_g, const void* ws, double count_a, double count_b, float* dgamma, float* dbeta,
+                         float* kk2, float* dy, void* stream);
+/* out (C) = column sums of x (R,C), fp64 accumulation: the bias gradient of netR_FC's last Linear (dout.sum(0)). */
+int facl_col_sums(const float* x, int64_t R, int C, float* out, void* stream);
 /* dWc (C,3) fp64 = dy^T centers: the centroid-xyz columns of the first per-centroid layer's weight gradient
  * (the input of net3DV_3 is torch.cat((yt, xt), 1), cn3d_model_conbag.py:219) in one streaming pass over dy */
 int facl_rows_center_wgrad(const float* dy, const float* centers, int64_t R, int C, double* dWc, void* ws,
@@ -259,6 +285,10 @@ int facl_gemm_dgrad(const float* dy, int64_t M, int N, const float* W, int ldw, 
                     void* stream);
 int facl_gemm_wgrad(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW,
                     float* slices, int nz, void* stream);
+/* facl_gemm_wgrad_acc: dW (N,K) += dy^T a -- the weight-gradient GEMM accumulating INTO its output (the second gradient path of
+ *   the loss's keys, d x += dsim^T @ [x ; x_global], without an add launch).  prec: 0 = fp32-grade (bf16x6), 1 = fp16 inputs,
+ *   2 = bf16x3 (the twins below).  Few rows only (M <= 8192, one wave of 64x64 workgroups): FACL_E_CONFIG otherwise. */
+int facl_gemm_wgrad_acc(const float* dy, const float* a, int64_t M, int N, int K, int lda, float* dW, int prec, void* stream);
 /* fp16-input twins (dense configuration, BASELINE configs[4] "fp16 MFMA point-MLP"): same arguments and fp32 storage;
  * the operands are rounded to fp16 while their tiles are staged and every multiply-add is ONE
  * v_mfma_f32_32x32x16_f16 product with fp32 accumulation (instead of the six bf16 products of the fp32-grade path). */
@@ -384,6 +414,11 @@ int facl_contrast(const float* sim, int R, int J, int B, int Bk, int nA, int nS,
  * anchor, is zero). */
 int facl_contrast_pair(const float* sim, int G, int B, int Bk, int J, const int64_t* order, int clip_offset,
                        float* dsim, double* losses, void* ws, void* stream);
+/* facl_contrast_pair that also writes the fp32 values of the loop body: losses32 = [loss_c, loss_circle, loss_circle + loss_c]
+ * (the fp32 sum of the two fp32 losses: `loss = loss_circle + loss_c`, cn3d_train_motion_GL.py:329), one finishing launch
+ * instead of a reduction, a cast and an add. */
+int facl_contrast_pair_sum(const float* sim, int G, int B, int Bk, int J, const int64_t* order, int clip_offset,
+                           float* dsim, double* losses, float* losses32, void* ws, void* stream);
 /* dst (R,J) = src scaled by *g1 in rows [0,R1) and by *g2 in rows [R1,R): the two upstream gradients (device scalars)
  * of loss_circle / loss_c applied to the shared d/dsim matrix. */
 int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J, const float* g1, const float* g2,

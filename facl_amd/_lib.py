@@ -167,6 +167,68 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- side stream: leaf work beside the critical chain (OPT-IN, measured slower) -------------------------------------------------
+# Parts of the step are chains of launch-latency-bound kernels that occupy a few CUs each (the FC head / loss block: ~20 us
+# GEMMs of one workgroup per CU, single-workgroup finalisations).  Work that nothing downstream of the chain waits for --
+# the weight / bias gradients of the FC head, F.normalize + mapping -- can go to ONE side stream per device (a parallel branch
+# of the captured graph), joined before its results are handed on.  MEASURED (round 5, same box, gpurun_out/r5c_ab.log):
+# 3.225 ms per step with the three branches against 3.11 ms without -- a fork / join inside a HIP graph costs far more than
+# the ~60 us of small kernels it takes off the chain (cross-queue dependencies instead of in-order dispatch).  Default off;
+# FACL_SIDE_STREAM=1 switches the branches on.
+SIDE_STREAM = os.environ.get("FACL_SIDE_STREAM", "0") != "0"
+_SIDE = {}
+
+
+class fork:
+    """``with fork() as f: ...`` -- the launches inside go to the device's side stream, which first waits for everything
+    issued so far on the current stream; ``f.join(*tensors)`` makes the current stream wait for the side stream (once per
+    fork; tensors allocated inside are marked as used by the current stream).  ``fork(enabled=False)`` is a no-op."""
+
+    def __init__(self, enabled=True):
+        self.on = bool(enabled) and SIDE_STREAM
+        self.joined = False
+
+    def __enter__(self):
+        if self.on:
+            self.main = torch.cuda.current_stream()
+            key = (self.main.device.index,)
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device=self.main.device)
+            self.side = _SIDE[key]
+            if self.side.cuda_stream == self.main.cuda_stream:       # already inside a fork: stay there
+                self.on = False
+                return self
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+            if exc[0] is not None:                                    # never leave a dangling branch behind an exception
+                self.main.wait_stream(self.side)
+                self.joined = True
+        return False
+
+    def join(self, *tensors):
+        if self.on and not self.joined:
+            self.main.wait_stream(self.side)
+            self.joined = True
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+
+
+_PENDING = []          # forks whose join was left to the caller of the model (facl_amd.cn3d_model_conbag: lazy_code)
+
+
+def join_pending():
+    while _PENDING:
+        f, ts = _PENDING.pop()
+        f.join(*ts)
+
+
 # ---- debug switch: poisoned scratch ------------------------------------------------------------------------------------
 # Every output / scratch tensor the host layer hands to a kernel is `torch.empty` (the kernels write every element
 # they later read).  With POISON on (FACL_POISON=1, or `with poisoned():`) those tensors and the partial-sum workspace are

@@ -182,7 +182,9 @@ class PointNet_Plus(nn.Module):
         stacked = _tail.fc_head(x_pre, self.gost, fc[0], fc[1], fc[3], training, self.bn_reduce_fn)
         self._stacked = stacked
         x, x_global = stacked[:M], stacked[M:]
-        x_nor, code = _tail.normalize_map(x, self.mapping.weight)              # :231-232
+        # :231-232.  `lazy_code` (set by a caller that does not read x_nor / code before it calls _lib.join_pending(): the
+        # training step without the SwAV / CLD terms): the kernel runs on the side stream beside the loss block
+        x_nor, code = _tail.normalize_map(x, self.mapping.weight, lazy=bool(getattr(self, "lazy_code", False)))
         return x, code, x_nor, x_global
 
 

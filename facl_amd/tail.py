@@ -420,12 +420,16 @@ class _FCHead(torch.autograd.Function):
         B = R - M
         dout = dout.contiguous()
         f32 = dict(dtype=torch.float32, device=y.device)
-        dW2 = gemm_wgrad(dout, a, prec=bp)
-        if dout.shape[1] % 4 == 0:
-            db2 = _lib.empty(dout.shape[1], **f32)
-            _lib.check(lib.facl_col_sums(_lib.ptr(dout), R, dout.shape[1], _lib.ptr(db2), _lib.stream()), "facl_col_sums")
-        else:
-            db2 = dout.sum(0)
+        # the weight / bias gradients are leaves: they run on the side stream beside the dgrad -> BatchNorm-backward chain
+        # (not under data parallelism: the chain holds a collective, and a graph segment must not end with an open branch)
+        side = ctx.reduce_fn is None
+        with _lib.fork(enabled=side) as f2:
+            dW2 = gemm_wgrad(dout, a, prec=bp)
+            if dout.shape[1] % 4 == 0:
+                db2 = _lib.empty(dout.shape[1], **f32)
+                _lib.check(lib.facl_col_sums(_lib.ptr(dout), R, dout.shape[1], _lib.ptr(db2), _lib.stream()), "facl_col_sums")
+            else:
+                db2 = dout.sum(0)
         dact = gemm_dgrad(dout, W2, prec=bp)
         dy = _lib.empty_like(y)
         if ctx.fused:
@@ -454,11 +458,14 @@ class _FCHead(torch.autograd.Function):
                 _lib.check(lib.facl_rows_bwd_apply(_lib.ptr(dact[r0:r1]), _lib.ptr(y[r0:r1]), r1 - r0, C, _lib.ptr(bnc),
                                                    _lib.ptr(kk[i]), _lib.ptr(dy[r0:r1]), _lib.stream()), "facl_rows_bwd_apply")
             dgamma, dbeta = dga[0] + dga[1], dbe[0] + dbe[1]
-        dW1 = gemm_wgrad(dy, h, prec=bp)
+        with _lib.fork(enabled=side) as f1:
+            dW1 = gemm_wgrad(dy, h, prec=bp)
         dh = gemm_dgrad(dy, W1, prec=bp)
         # dL/dx_pre = dh[:M] + (dh[M:] routed to the winning view's row of each (clip, channel))
         _lib.check(lib.facl_viewmax_bwd_add(dh[M:].data_ptr(), _lib.ptr(arg), ctx.G, B, dh.shape[1], _lib.ptr(dh), _lib.stream()),
                    "facl_viewmax_bwd_add")
+        f2.join(dW2, db2)
+        f1.join(dW1)
         # d(bias of the first Linear) is identically zero in front of a train-mode BN: None leaves it untouched
         return dh[:M], None, dW1, None, dgamma, dbeta, None, dW2, db2, None, None
 
@@ -475,7 +482,7 @@ class _NormalizeMap(torch.autograd.Function):
     live loss does not use these outputs; the backward (SwAV branch, user code) is the closed form in tensor algebra."""
 
     @staticmethod
-    def forward(ctx, x, Wm):
+    def forward(ctx, x, Wm, lazy=False):
         lib = _lib.load_library()
         _lib.require_cuda(x)
         x, Wm = x.contiguous(), Wm.contiguous()
@@ -483,8 +490,13 @@ class _NormalizeMap(torch.autograd.Function):
         K = Wm.shape[0]
         xn = _lib.empty_like(x)
         code = _lib.empty((M, K), dtype=torch.float32, device=x.device)
-        _lib.check(lib.facl_normalize_map(_lib.ptr(x), M, C, _lib.ptr(Wm), K, _lib.ptr(xn), _lib.ptr(code), _lib.stream()),
-                   "facl_normalize_map")
+        # `lazy`: the caller (the training step, whose loss does not read these outputs) joins the side stream itself
+        # (_lib.join_pending) -- the kernel then runs beside the loss block instead of in front of it
+        with _lib.fork(enabled=lazy) as f:
+            _lib.check(lib.facl_normalize_map(_lib.ptr(x), M, C, _lib.ptr(Wm), K, _lib.ptr(xn), _lib.ptr(code), _lib.stream()),
+                       "facl_normalize_map")
+        if f.on:
+            _lib._PENDING.append((f, (xn, code)))
         ctx.save_for_backward(x, xn, Wm)
         return xn, code
 
@@ -495,11 +507,13 @@ class _NormalizeMap(torch.autograd.Function):
         dWm = dcode.t() @ xn
         nrm = x.norm(dim=1, keepdim=True).clamp_min(1e-12)
         dx = (dxn_t - xn * (dxn_t * xn).sum(1, keepdim=True)) / nrm
-        return dx, dWm
+        return dx, dWm, None
 
 
-def normalize_map(x, mapping_weight):
-    return _NormalizeMap.apply(x, mapping_weight)
+def normalize_map(x, mapping_weight, lazy=False):
+    """lazy=True: the kernel runs on the side stream and the CALLER must call _lib.join_pending() before x_nor / code are
+    read (or at the end of its step); the default joins nothing because nothing was forked."""
+    return _NormalizeMap.apply(x, mapping_weight, lazy)
 
 
 class _ViewMax(torch.autograd.Function):

@@ -173,6 +173,8 @@ class ContrastiveStep:
 
     def _encode_and_step(self, xt, yt, B, order):
         netR, G = self.netR, self.G
+        # x_nor / code feed the SwAV / CLD terms only: without them F.normalize + mapping run beside the loss block
+        netR.lazy_code = not (self.swa_if or self.cld_if) and not fdist.is_distributed()
         x, code, x_nor, x_global = netR(xt, yt, 1)                                 # :234
         x_keys = fdist.all_gather_view_major(x, G)
         off = self.rank * B
@@ -197,6 +199,8 @@ class ContrastiveStep:
         loss.backward(self._one)
         if self.grad_sync is not None:
             self.grad_sync.finish()                                                # tail bucket overlapped with the SA backward
+        from . import _lib as _flib
+        _flib.join_pending()                                                       # the side-stream branch of x_nor / code
         self.optimizer.step()
         return loss, loss_c, loss_circle
 

@@ -168,7 +168,12 @@ __device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, u
     const f32x2v v = {x0, x1};
     const f16x2h h = __builtin_convertvector(v, f16x2h);                               // round to nearest even
     hi = __builtin_bit_cast(unsigned, h);
-    const f32x2v r = {sub_f32(x0, (float)h[0]), sub_f32(x1, (float)h[1])};            // exact
+    // residuals x - float(h): ONE v_fma_mix_f32 each (h's half converted inside the instruction, times -1, plus x: exact, and
+    // identical to v_cvt_f32_f16 + v_sub_f32, which the compiler emitted for the plain expression) -- 4 VALU per pair, not 6
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    const f32x2v r = {r0, r1};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2h));
 }
 __device__ __forceinline__ f16x8h as_f16x8(unsigned a, unsigned b, unsigned c, unsigned d) {

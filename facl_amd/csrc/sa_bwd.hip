@@ -493,6 +493,165 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
 }
 
 // ---------------------------------------------------------------------------------------------
+// bwd_w3, round 5: TWO waves per unit, free-running.  k_sa_bwd_w3 keeps 4 x 64 sparse accumulators per lane (474 registers:
+// one wave per SIMD, every LDS / HBM wait exposed -- PMC: 51 % of the wave cycles parked).  Here waves (2p, 2p + 1) of a
+// workgroup walk the SAME units; each builds the unit's whole a2 tile in its OWN LDS tile (the partner's second read of the
+// 16 KiB comes out of the L2; no barrier, no hand-off) and takes HALF of the work on it: wave `role` the sparse rows of
+// channels e in {2 role, 2 role + 1} (128 accumulators), the diagonal Gram tile G[role][role] and half the k-steps of
+// G[0][1] (18 of the 36 MFMAs).  <= 256 registers -> two waves per SIMD, and the two waves of a SIMD (w, w + 4) belong to
+// different pairs, i.e. sit in different phases of different units.  A first form with ONE shared tile per pair, each wave
+// building half of it behind a workgroup barrier per unit, measured 0.33 ms against the one-wave kernel's 0.267
+// (gpurun_out/r5e_ab.log): eight waves in lockstep wait for memory together.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_sa_bwd_w3p(const float* __restrict__ y2f, int nunits, const float* __restrict__ bnc2, const float* __restrict__ coef,
+                  const unsigned char* __restrict__ arg, double* __restrict__ part, const unsigned* __restrict__ a2amax) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int seA2 = h3_se_of(a2amax);
+    const float sA2 = pow2_biased(seA2), GU = h3_unscale(seA2, seA2), iA2 = pow2_biased(254 - seA2);
+    float4* tab = lds4;                                         // scale2, shift2: 2 x 16 float4
+    float* base = reinterpret_cast<float*>(lds4 + 32);
+    // loop: 8 tiles of [64][TP], one per wave; afterwards the same bytes hold the combine areas
+    float* comb = base;                                         // [256][65]
+    float* gcomb = comb + 256 * 65;                             // [64][64]
+    float* scomb = gcomb + 64 * 64;                             // [64]
+    const int lane = lane_id(), h = lane >> 5, q = lane & 31, wave = threadIdx.x >> 6;
+    const int pair = wave >> 1, role = wave & 1;
+    float* T = base + wave * (64 * TP);
+    if (threadIdx.x < 32) {
+        float4 t = reinterpret_cast<const float4*>(bnc2 + 128)[threadIdx.x];
+        t.x *= sA2; t.y *= sA2; t.z *= sA2; t.w *= sA2;
+        tab[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const float4* sc2 = tab; const float4* sh2 = tab + 16;
+    const int pair_g = blockIdx.x * 4 + pair, npairs = gridDim.x * 4;
+
+    float accs[2][64];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < 64; ++k) accs[e][k] = 0.f;
+    // Gram tiles of this wave: gm = G[role][role] over all 64 positions, gx = its half (k-steps 2 role, 2 role + 1) of G[0][1]
+    f32x16 gm, gx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gm[r] = 0.f; gx[r] = 0.f; }
+    float s2m = 0.f;                                            // sum over positions of a2[:, 32 role + q] (this lane: its h-half of them)
+
+    for (int u = pair_g; u < nunits; u += npairs) {
+        {
+            const float* tile = y2f + (size_t)u * FACL_UNIT_ELEMS;
+            float4 yn[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yn[i] = *reinterpret_cast<const float4*>(tile + (i * 64 + lane) * 4);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 y = yn[(ct * 2 + rt) * 4 + r4];
+                        const float4 sc = sc2[8 * rt + 2 * r4 + h], sh = sh2[8 * rt + 2 * r4 + h];
+                        float4 a;
+                        a.x = fmaxf(fmaf(sc.x, y.x, sh.x), 0.f); a.y = fmaxf(fmaf(sc.y, y.y, sh.y), 0.f);
+                        a.z = fmaxf(fmaf(sc.z, y.z, sh.z), 0.f); a.w = fmaxf(fmaf(sc.w, y.w, sh.w), 0.f);
+                        *reinterpret_cast<float4*>(&T[(32 * ct + q) * TP + 32 * rt + 8 * r4 + 4 * h]) = a;
+                    }
+        }
+        float cfv[2];
+        int psv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            cfv[e] = coef[(size_t)u * 256 + 64 * (2 * role + e) + lane];
+            psv[e] = arg[(size_t)u * 256 + 64 * (2 * role + e) + lane];
+        }
+        WAVE_LDS_FENCE();
+        // Gram on fp16x3 (as k_sa_bwd_w3): operand fragments = columns of the tile (lane = channel, k-slots = positions
+        // 16 ks + 8 h + t).  This wave: its diagonal tile over all four k-steps, the off-diagonal tile over two of them.
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float vm[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vm[t] = T[(16 * ks + 8 * h + t) * TP + 32 * role + q];
+            unsigned hm[4], lm[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s2m += vm[2 * t] + vm[2 * t + 1];
+                split_pair_h(vm[2 * t], vm[2 * t + 1], hm[t], lm[t]);
+            }
+            const f16x8h HM = as_f16x8(hm[0], hm[1], hm[2], hm[3]), LM = as_f16x8(lm[0], lm[1], lm[2], lm[3]);
+            gm = MFMA_F16(LM, HM, gm); gm = MFMA_F16(HM, LM, gm); gm = MFMA_F16(HM, HM, gm);         // smallest terms first
+            if ((ks >> 1) == role) {                            // wave-uniform
+                float vo[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) vo[t] = T[(16 * ks + 8 * h + t) * TP + 32 * (role ^ 1) + q];   // (role ^ 1, not 1 - role: a subtraction keeps the constant part out of the ds_read offset field)
+                unsigned ho[4], lo[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) split_pair_h(vo[2 * t], vo[2 * t + 1], ho[t], lo[t]);
+                const f16x8h HO = as_f16x8(ho[0], ho[1], ho[2], ho[3]), LO = as_f16x8(lo[0], lo[1], lo[2], lo[3]);
+                if (role == 0) {                                // G[0][1] = sum a2[:, 0:32]^T a2[:, 32:64]: A = block 0, B = block 1
+                    gx = MFMA_F16(LM, HO, gx); gx = MFMA_F16(HM, LO, gx); gx = MFMA_F16(HM, HO, gx);
+                } else {
+                    gx = MFMA_F16(LO, HM, gx); gx = MFMA_F16(HO, LM, gx); gx = MFMA_F16(HO, HM, gx);
+                }
+            }
+        }
+        // sparse part of dW3: lane owns channels 64 (2 role + e) + lane and adds coef * a2[arg][:] (one LDS row each)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float4* row = reinterpret_cast<const float4*>(&T[psv[e] * TP]);
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const float4 v = row[k4];
+                accs[e][4 * k4 + 0] = fmaf(cfv[e], v.x, accs[e][4 * k4 + 0]);
+                accs[e][4 * k4 + 1] = fmaf(cfv[e], v.y, accs[e][4 * k4 + 1]);
+                accs[e][4 * k4 + 2] = fmaf(cfv[e], v.z, accs[e][4 * k4 + 2]);
+                accs[e][4 * k4 + 3] = fmaf(cfv[e], v.w, accs[e][4 * k4 + 3]);
+            }
+        }
+        WAVE_LDS_FENCE();      // next unit overwrites T
+    }
+    __syncthreads();                                            // the tiles are dead: their bytes become the combine areas
+    const float s2t = s2m + __shfl_xor(s2m, 32, 64);
+    // sparse rows, diagonal Gram tiles and sum a2: the two roles own disjoint halves, the four pairs add in pair order;
+    // the off-diagonal tile G[0][1] has a partial sum in all eight waves, added in wave order
+    for (int w = 0; w < 4; ++w) {
+        if (pair == w) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    float* d = &comb[(64 * (2 * role + e) + lane) * 65 + k];
+                    *d = (w == 0 ? 0.f : *d) + accs[e][k] * iA2;
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* d = &gcomb[(32 * role + rowmap(r, h)) * 64 + 32 * role + q];
+                *d = (w == 0 ? 0.f : *d) + gm[r] * GU;
+            }
+            if (h == 0) scomb[32 * role + q] = (w == 0 ? 0.f : scomb[32 * role + q]) + s2t * iA2;
+        }
+        __syncthreads();
+    }
+    for (int w = 0; w < 8; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* d = &gcomb[rowmap(r, h) * 64 + 32 + q];
+                *d = (w == 0 ? 0.f : *d) + gx[r] * GU;
+            }
+        }
+        __syncthreads();
+    }
+    double* row = part + (size_t)blockIdx.x * W3_V;
+    for (int i = threadIdx.x; i < 256 * 64; i += 512) row[i] = (double)comb[(i >> 6) * 65 + (i & 63)];
+    for (int i = threadIdx.x; i < 64 * 64; i += 512) {
+        const int a = i >> 6, b = i & 63;
+        row[256 * 64 + i] = (double)((a >= 32 && b < 32) ? gcomb[b * 64 + a] : gcomb[i]);     // lower-left = upper-right^T
+    }
+    if (threadIdx.x < 64) row[256 * 64 + 64 * 64 + threadIdx.x] = (double)scomb[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
 // bwd2.  Output row per wave: [ dW2 (64 x 64, [c2][c1]) | R1 (8 x 64, rows: x_0..x_{D-1}, 1, 0..) ] = 4608 doubles
 constexpr int B2_V = 64 * 64 + 8 * 64;
 
@@ -705,11 +864,22 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
-    const size_t lds = 32 * sizeof(float4) + (256 * 65 + 64 * 64 + 64 + 4 * 64 * TP) * sizeof(float);
-    static bool attr_done[64] = {};
-    const void* fns[1] = {(const void*)k_sa_bwd_w3};
-    if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, (int)lds)) return rc;
-    hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, a2amax);
+    // round 5: two waves per unit (k_sa_bwd_w3p) unless FACL_BWD_W3_PAIR=0 selects the one-wave-per-unit kernel (A/B)
+    static const int pairk = getenv("FACL_BWD_W3_PAIR") ? atoi(getenv("FACL_BWD_W3_PAIR")) : 1;
+    if (pairk) {
+        const size_t tiles = (size_t)8 * 64 * TP, combs = (size_t)256 * 65 + 64 * 64 + 64;
+        const size_t lds = 32 * sizeof(float4) + (tiles > combs ? tiles : combs) * sizeof(float);
+        static bool attr_done[64] = {};
+        const void* fns[1] = {(const void*)k_sa_bwd_w3p};
+        if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, (int)lds)) return rc;
+        hipLaunchKernelGGL(k_sa_bwd_w3p, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, a2amax);
+    } else {
+        const size_t lds = 32 * sizeof(float4) + (256 * 65 + 64 * 64 + 64 + 4 * 64 * TP) * sizeof(float);
+        static bool attr_done[64] = {};
+        const void* fns[1] = {(const void*)k_sa_bwd_w3};
+        if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, (int)lds)) return rc;
+        hipLaunchKernelGGL(k_sa_bwd_w3, dim3(grid), dim3(256), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, a2amax);
+    }
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, grid, W3_V, out, st);

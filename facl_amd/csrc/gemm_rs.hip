@@ -202,21 +202,23 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <bool PRO, bool SEG, bool BST, bool H3 = false>
-__global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
+// WV = waves per workgroup: 4 (128 rows, two workgroups per CU: the default) or 8 (256 rows, one workgroup per CU: every k-step
+// of weight planes serves twice the rows; opt-in experiment, measured equal: rs_waves below)
+template <bool PRO, bool SEG, bool BST, bool H3 = false, int WV = RS_WAVES>
+__global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) {
     constexpr int NPL = H3 ? 2 : 3;                                     // planes per fragment (fp16x3 / bf16x6, common.h)
-    constexpr int WPP = RS_CT * NPL / RS_WAVES;                         // 1-KiB weight pieces a wave issues per k-step
+    constexpr int WPP = RS_CT * NPL / WV;                         // 1-KiB weight pieces a wave issues per k-step
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* const wring = lds;
     char* const abuf = lds + RS_LDS_W + wave * RS_ASLOT;
-    float* const tab = reinterpret_cast<float*>(lds + RS_LDS_W + RS_LDS_A);
+    float* const tab = reinterpret_cast<float*>(lds + RS_LDS_W + WV * RS_ASLOT);
     const unsigned wring_a = __builtin_amdgcn_readfirstlane(lds_addr(wring));
     const unsigned abuf_a = __builtin_amdgcn_readfirstlane(lds_addr(abuf));
     const RsTile tile = rs_tile();
     const int cb = tile.x;
-    const int row0 = (tile.y * RS_WAVES + wave) * 32;
+    const int row0 = (tile.y * WV + wave) * 32;
     const int nks = g.K >> 4, nst = g.K >> 5;
     const int nks_all = nks + (g.centers ? 1 : 0);
     int seA = 127;                                                      // fp16x3: biased exponent of the A operand's scale
@@ -224,12 +226,12 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     const float sA = pow2_biased(seA);
 
     if (PRO) {
-        for (int i = tid; i < g.K; i += 64 * RS_WAVES) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
+        for (int i = tid; i < g.K; i += 64 * WV) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
         __syncthreads();
     }
 
     // ---- DMA issue helpers (wave-uniform control flow; VM-counter bookkeeping in the pipeline comment below)
-    // this wave's RS_CT / RS_WAVES column tiles are RS_WPP consecutive 1-KiB pieces of a k-step
+    // this wave's share of the k-step's column tiles: WPP consecutive 1-KiB pieces
     const uint4* wsrc = g.Wp + ((size_t)(RS_CT * cb) * NPL + wave * WPP) * 64 + lane;
     const size_t wstep = (size_t)g.NT * NPL * 64;                                      // uint4 per k-step
     auto issueW = [&](int j) {
@@ -409,7 +411,8 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     // its y tile in the same way, reversed (4 wide loads -> image -> 16 ds_read_b32).
     // Statistics / max-pool hand-off areas live in the weight-ring slot that the final k-step does NOT read.
     float* const stg = reinterpret_cast<float*>(abuf);
-    char* const freeslot = wring + (((nks_all - 1) & 1) ^ 1) * RS_WSLOT;
+    // (8-wave workgroups: 8 x 6 KiB do not fit a ring slot; they have an area of their own behind the prologue tables)
+    char* const freeslot = WV == 8 ? lds + RS_LDS_W + WV * RS_ASLOT + 2 * RS_KPRO * 4 : wring + (((nks_all - 1) & 1) ^ 1) * RS_WSLOT;
     float* const wstat = reinterpret_cast<float*>(freeslot + wave * 6144);       // (sum, sumsq) per column: 2 KiB
     float* const wbest = wstat + 512;                                            // SEG, odd waves: (max, arg): 2 KiB
     float* const ystg = wstat + 512;                                             // BST: y tile image, 4 KiB
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(64 * RS_WAVES, 2) void k_gemm_rs(RsArgs g) {
     if (g.part && tid < 256) {                                         // the waves in wave order, fp64: one partial row per workgroup
         double s = 0.0, sq = 0.0;
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; ++w) {
+        for (int w = 0; w < WV; ++w) {
             const float* ps = reinterpret_cast<const float*>(freeslot + w * 6144);
             s += (double)ps[2 * tid]; sq += (double)ps[2 * tid + 1];
         }
@@ -735,8 +738,19 @@ __global__ void k_wg_sum_slices(const float* __restrict__ part, int nz, long lon
     }
 }
 
+constexpr int RS_LDS8 = RS_LDS_W + 8 * RS_ASLOT + 2 * RS_KPRO * 4 + 8 * 6144;     // 132 KiB: one 8-wave workgroup per CU
+
+// waves per workgroup of the fp16x3 kernels.  FACL_RS_W8=1: 8-wave workgroups (256 rows per k-step of weight planes: half the
+// plane re-reads).  Measured equal or slower (round 5, same box, bit-identical results: forward 49152x512x1024 0.182 vs
+// 0.184 ms, dgrad 1024->512 0.187 vs 0.176, step 3.023 vs 3.006 ms; gpurun_out/r5g_ab.log) -- the weight-plane traffic is
+// not what bounds these kernels.  Default: 4 waves, two workgroups per CU.
+int rs_waves(int h3) {
+    static const int w8 = getenv("FACL_RS_W8") ? atoi(getenv("FACL_RS_W8")) : 0;
+    return (h3 && w8) ? 8 : RS_WAVES;
+}
+
 int rs_launch(const RsArgs& g, hipStream_t st) {
-    // the 68 KiB dynamic-LDS attribute is per device: one flag per device ordinal (a process may drive several devices, and a
+    // the dynamic-LDS attribute is per device: one flag per device ordinal (a process may drive several devices, and a
     // forward on the main thread can race a backward on the autograd thread: the worst case sets the attribute twice)
     static bool attr_done_dev[64] = {};
     int dev = 0;
@@ -752,7 +766,24 @@ int rs_launch(const RsArgs& g, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
             if (e != hipSuccess) return (int)e;
         }
+        const void* fns8[5] = {(const void*)k_gemm_rs<false, false, true, true, 8>, (const void*)k_gemm_rs<false, false, false, true, 8>,
+                               (const void*)k_gemm_rs<true, false, false, true, 8>, (const void*)k_gemm_rs<false, true, false, true, 8>,
+                               (const void*)k_gemm_rs<true, true, false, true, 8>};
+        for (int i = 0; i < 5; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns8[i], hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS8);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_done = true;
+    }
+    if (rs_waves(g.h3) == 8) {
+        dim3 grid(g.N / 256, (g.M + 255) / 256);
+        const dim3 blk(512);
+        if (g.by) hipLaunchKernelGGL((k_gemm_rs<false, false, true, true, 8>), grid, blk, RS_LDS8, st, g);
+        else if (g.pscale && g.smax) hipLaunchKernelGGL((k_gemm_rs<true, true, false, true, 8>), grid, blk, RS_LDS8, st, g);
+        else if (g.pscale) hipLaunchKernelGGL((k_gemm_rs<true, false, false, true, 8>), grid, blk, RS_LDS8, st, g);
+        else if (g.smax) hipLaunchKernelGGL((k_gemm_rs<false, true, false, true, 8>), grid, blk, RS_LDS8, st, g);
+        else hipLaunchKernelGGL((k_gemm_rs<false, false, false, true, 8>), grid, blk, RS_LDS8, st, g);
+        return facl_launch_status();
     }
     dim3 grid(g.N / 256, (g.M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
     const dim3 blk(64 * RS_WAVES);
@@ -850,7 +881,8 @@ extern "C" int facl_gemm_rs_fwd(const float* a, int64_t M, int K, const void* pl
     if ((sgn == nullptr) != (ymax == nullptr) || (sgn == nullptr) != (arg == nullptr)) return FACL_E_NULL;
     if (sgn && (M & 63)) return FACL_E_SHAPE;
     if (((uintptr_t)a | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
-    const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
+    const int rpw = 32 * rs_waves(half ? 1 : 0);
+    const int prow = (int)((M + rpw - 1) / rpw);
     if (sums && (size_t)prow * N * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(N, K, centers ? 1 : 0));
@@ -885,7 +917,8 @@ extern "C" int facl_gemm_rs_dgrad_bnstats(const float* dy, int64_t M, int N, con
     if (!dy || !planes || !da || !y || !bnc || !sums || !ws || (half && !amax)) return FACL_E_NULL;
     if (!facl_gemm_rs_supported(M, N, K)) return FACL_E_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)planes) & 15) return FACL_E_ALIGN;
-    const int prow = (int)((M + 32 * RS_WAVES - 1) / (32 * RS_WAVES));
+    const int rpw = 32 * rs_waves(half ? 1 : 0);
+    const int prow = (int)((M + rpw - 1) / rpw);
     if ((size_t)prow * K * 2 * sizeof(double) > ((size_t)facl_ws_bytes() - FACL_WS_TICKET_BYTES)) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int* wse = (const int*)((const char*)planes + rs_planes_only_bytes(K, N, 0));

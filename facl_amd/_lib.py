@@ -171,7 +171,7 @@ def stream():
 # Parts of the step are chains of launch-latency-bound kernels that occupy a few CUs each (the FC head / loss block: ~20 us
 # GEMMs of one workgroup per CU, single-workgroup finalisations).  Work that nothing downstream of the chain waits for --
 # the weight / bias gradients of the FC head, F.normalize + mapping -- can go to ONE side stream per device (a parallel branch
-# of the captured graph), joined before its results are handed on.  MEASURED (round 5, same box, gpurun_out/r5c_ab.log):
+# of the captured graph), joined before its results are handed on.  MEASURED (round 4, same box, gpurun_out/r5c_ab.log):
 # 3.225 ms per step with the three branches against 3.11 ms without -- a fork / join inside a HIP graph costs far more than
 # the ~60 us of small kernels it takes off the chain (cross-queue dependencies instead of in-order dispatch).  Default off;
 # FACL_SIDE_STREAM=1 switches the branches on.

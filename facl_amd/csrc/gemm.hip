@@ -1174,7 +1174,7 @@ extern "C" int facl_gemm_wgrad_x3(const float* dy, const float* a, int64_t M, in
     return gemm_wgrad_p(dy, a, M, N, K, lda, dW, slices, nz, stream, 2);
 }
 
-// ---- round 5 (prec: 0 = fp32-grade, 1 = fp16 inputs, 2 = bf16x3) -----------------------------------------------------------------
+// ---- round 4, late (prec: 0 = fp32-grade, 1 = fp16 inputs, 2 = bf16x3) -----------------------------------------------------------------
 // dW (N,K) += dy^T a: the weight-gradient GEMM accumulating INTO its output -- the second gradient path of the loss's keys
 // (utils_my._ContrastivePair.backward: d x += dsim^T @ stacked) without a separate add launch.  Few rows only (the
 // workgroup-level split-K kernel writes its tile once): FACL_E_CONFIG otherwise, the caller then adds itself.

@@ -741,7 +741,7 @@ __global__ void k_wg_sum_slices(const float* __restrict__ part, int nz, long lon
 constexpr int RS_LDS8 = RS_LDS_W + 8 * RS_ASLOT + 2 * RS_KPRO * 4 + 8 * 6144;     // 132 KiB: one 8-wave workgroup per CU
 
 // waves per workgroup of the fp16x3 kernels.  FACL_RS_W8=1: 8-wave workgroups (256 rows per k-step of weight planes: half the
-// plane re-reads).  Measured equal or slower (round 5, same box, bit-identical results: forward 49152x512x1024 0.182 vs
+// plane re-reads).  Measured equal or slower (round 4, same box, bit-identical results: forward 49152x512x1024 0.182 vs
 // 0.184 ms, dgrad 1024->512 0.187 vs 0.176, step 3.023 vs 3.006 ms; gpurun_out/r5g_ab.log) -- the weight-plane traffic is
 // not what bounds these kernels.  Default: 4 waves, two workgroups per CU.
 int rs_waves(int h3) {

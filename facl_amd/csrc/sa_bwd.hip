@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_sa_bwd_w3(const float* __restrict__ y2f
 }
 
 // ---------------------------------------------------------------------------------------------
-// bwd_w3, round 5: TWO waves per unit, free-running.  k_sa_bwd_w3 keeps 4 x 64 sparse accumulators per lane (474 registers:
+// bwd_w3, round 4 (late): TWO waves per unit, free-running.  k_sa_bwd_w3 keeps 4 x 64 sparse accumulators per lane (474 registers:
 // one wave per SIMD, every LDS / HBM wait exposed -- PMC: 51 % of the wave cycles parked).  Here waves (2p, 2p + 1) of a
 // workgroup walk the SAME units; each builds the unit's whole a2 tile in its OWN LDS tile (the partner's second read of the
 // 16 KiB comes out of the L2; no barrier, no hand-off) and takes HALF of the work on it: wave `role` the sparse rows of
@@ -864,7 +864,7 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
     if (nunits < 1 || nunits > 0x7fffffff) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
-    // round 5: two waves per unit (k_sa_bwd_w3p) unless FACL_BWD_W3_PAIR=0 selects the one-wave-per-unit kernel (A/B)
+    // round 4 (late): two waves per unit (k_sa_bwd_w3p) unless FACL_BWD_W3_PAIR=0 selects the one-wave-per-unit kernel (A/B)
     static const int pairk = getenv("FACL_BWD_W3_PAIR") ? atoi(getenv("FACL_BWD_W3_PAIR")) : 1;
     if (pairk) {
         const size_t tiles = (size_t)8 * 64 * TP, combs = (size_t)256 * 65 + 64 * 64 + 64;

@@ -324,7 +324,7 @@ class _FCHead(torch.autograd.Function):
     the cat / split launches of both directions; in the backward the view-max gradient is scattered straight into the
     rows of dL/dx_pre (no (G*B, C) zero tensor, no autograd accumulation kernel).
 
-    Round 5: this block is ~50 launches of a few microseconds each around nine ~20 us GEMMs, i.e. launch latency.  The
+    Round 4 (second session): this block is ~50 launches of a few microseconds each around nine ~20 us GEMMs, i.e. launch latency.  The
     two-segment BatchNorm is three launches per direction (csrc/fchead.hip: fp64 slice statistics
     -> both finalisations -> one apply; backward: slice sums -> constants + parameter gradients of both segments
     -> one apply) instead of nine / eleven, the view maximum fills the stacked input in the launch that reads it, and the

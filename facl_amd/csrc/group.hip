@@ -6,11 +6,12 @@
 //
 // Roofline: HBM.  Algorithmic bytes per cloud = N*D*4 (read) + S*K*(4 + 4*D) + S*12 (write).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int GROUP_THREADS = 256;           // 4 waves
-constexpr int CENTROIDS_PER_WG = 16;         // 4 per wave
+constexpr int CENTROIDS_PER_WG = 16;         // 4 per wave (the default; the kernel takes the count as a template argument)
 constexpr int CKEYS = 4;                     // keys per lane once the candidate set fits (radix select, second phase)
 
 // dist^2 exactly as the reference's fp32 chain: (dx*dx + dy*dy) + dz*dz, no FMA contraction.
@@ -19,7 +20,7 @@ __device__ __forceinline__ float dist2_exact(float px, float py, float pz, float
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-template <int D, int NPL>
+template <int D, int NPL, int CPW = CENTROIDS_PER_WG>
 __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict__ points, int N, int S,
                                                          int K, float r2, int32_t* __restrict__ idx_out,
                                                          float* __restrict__ xt_out, float* __restrict__ yt_out,
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
     const unsigned long long lt = lanemask_lt();
 
     uint32_t eguess = 122;                    // wave-persistent exponent guess of the K-th distance^2 (2^-5 .. 2^-4 to start with)
-    for (int ci = wave; ci < CENTROIDS_PER_WG; ci += GROUP_THREADS / 64) {
-        const int c = blockIdx.x * CENTROIDS_PER_WG + ci;       // wave-uniform
+    for (int ci = wave; ci < CPW; ci += GROUP_THREADS / 64) {
+        const int c = blockIdx.x * CPW + ci;                     // wave-uniform
         if (c >= S) break;
         const float cx = xs[c], cy = ys[c], cz = zs[c];
 
@@ -210,9 +211,20 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
 template <int D, int NPL>
 int launch_group(const float* points, int M, int N, int S, int K, float r2, int32_t* idx, float* xt, float* yt,
                  int clipB, hipStream_t st) {
-    dim3 grid((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M);
     const size_t lds = (size_t)N * 4 * sizeof(float) + 4 * 64 * CKEYS * sizeof(uint32_t);   // cloud (SoA) + one key / emission slot per wave
-    hipLaunchKernelGGL((k_group<D, NPL>), grid, dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    // centroids per workgroup (A/B knob FACL_GROUP_CPW: 16 = four workgroups stage each cloud, 32 = two, 64 = one)
+    static const int cpw = getenv("FACL_GROUP_CPW") ? atoi(getenv("FACL_GROUP_CPW")) : CENTROIDS_PER_WG;
+    if (cpw == 32) {
+        hipLaunchKernelGGL((k_group<D, NPL, 32>), dim3((S + 31) / 32, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    } else if (cpw == 8) {
+        hipLaunchKernelGGL((k_group<D, NPL, 8>), dim3((S + 7) / 8, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    } else if (cpw == 4) {
+        hipLaunchKernelGGL((k_group<D, NPL, 4>), dim3((S + 3) / 4, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    } else if (cpw == 64) {
+        hipLaunchKernelGGL((k_group<D, NPL, 64>), dim3((S + 63) / 64, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    } else {
+        hipLaunchKernelGGL((k_group<D, NPL>), dim3((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    }
     return facl_launch_status();
 }
 

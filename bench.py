@@ -177,7 +177,7 @@ def kernel_models(a, K=64):
                              flops=nunits * 2.0 * 64 * 64 * 256, bytes=nunits * (y2 + 1024.0 + 256.0)),
         "facl_sa_bwd1": dict(kernel="k_sa_bwd1", pipe="fp16x3", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
                              bytes=nunits * (2.0 * y2 + 1024 + 256)),
-        "facl_sa_bwd_w3": dict(kernel="k_sa_bwd_w3", pipe="fp16x3", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
+        "facl_sa_bwd_w3": dict(kernel="k_sa_bwd_w3p" if os.environ.get("FACL_BWD_W3_PAIR", "1") != "0" else "k_sa_bwd_w3", pipe="fp16x3", flops=nunits * (2.0 * 64 * 64 * 64 + 2.0 * 256 * 64),
                                bytes=nunits * (y2 + 1024.0 + 256.0)),
         # da1 = dy2 W2 (2*64*64) + dW2 += dy2^T a1 (2*64*64) + R1 += [x|1]^T dz1 (2*64*4) per position
         "facl_sa_bwd2": dict(kernel="k_sa_bwd2" if bwd2_f32 else "k_sa_bwd2_sb",

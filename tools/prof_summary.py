@@ -18,7 +18,9 @@ def main():
         k = ("rocBLAS GEMM" if "Cijk" in n else "torch small ops" if ("at::" in n or "rocclr" in n) else
              "SA-MLP HIP" if ("k_sa_" in n or "k_x_mom" in n) else "tail rows HIP" if ("k_rows" in n or "k_segmax" in n)
              else "group HIP" if ("k_group" in n or "k_fps" in n) else "loss HIP" if "k_contrast" in n else
-             "finalize HIP" if ("k_reduce" in n or "k_bn" in n or "k_l1tab" in n) else
+             "finalize HIP" if ("k_reduce" in n or "k_bn" in n or "k_l1tab" in n or "k_fc_finalize" in n or "k_fc_bwd_consts" in n
+                                or "k_loss_finish" in n or "k_fc_reduce" in n) else
+             "tail rows HIP" if ("k_fc_" in n or "k_col_sums" in n or "k_viewmax" in n or "k_normalize" in n or "k_scale_rows" in n) else
              "GEMM HIP (row-streamed)" if ("k_gemm_rs" in n or "k_wgrad_rs" in n or "k_rs_planes" in n or "k_wg_sum" in n) else
              "GEMM HIP (LDS-staged)" if ("k_gemm" in n or "k_sum_slices" in n) else "other")
         cat[k] += t

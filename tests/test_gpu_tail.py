@@ -164,3 +164,117 @@ def test_fused_adam_equals_torch_adam():
         assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max())
     sd = oa.state_dict()
     assert int(sd["state"][0]["step"]) == 6 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def _fc_head_reference_fp64(x_pre, G, W1, b1, gamma, beta, W2, b2, rm, rv, momentum=0.1, eps=1e-5):
+    """netR_FC applied the reference's way (cn3d_model_conbag.py:225-229): once on the view rows, once on the per-clip view
+    maximum, each with its own batch statistics; the running buffers are updated twice, view rows first.  fp64 torch."""
+    M, C = x_pre.shape
+    B = M // G
+    xg = x_pre.view(G, B, C).max(dim=0).values
+    outs = []
+    for h in (x_pre, xg):
+        y = h @ W1.t() + b1
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        n = y.shape[0]
+        rm = (1 - momentum) * rm + momentum * mean.detach()
+        rv = (1 - momentum) * rv + momentum * (var.detach() * n / max(n - 1, 1))
+        a = torch.relu((y - mean) / torch.sqrt(var + eps) * gamma + beta)
+        outs.append(a @ W2.t() + b2)
+    return torch.cat(outs, 0), rm, rv
+
+
+@pytest.mark.parametrize("G,B,Cin,C,dim", [(24, 32, 1024, 1024, 512), (8, 4, 64, 128, 32), (2, 16, 32, 64, 16)])
+def test_fc_head_two_segment_batchnorm_vs_two_fp64_calls(G, B, Cin, C, dim):
+    """tail.fc_head on the fused two-segment BatchNorm kernels (csrc/fchead.hip: slice statistics -> both finalisations ->
+    one apply; backward: slice sums -> constants + gamma / beta gradients of both segments -> one apply; the view maximum
+    written into the stacked input by the launch that reads it; the bias gradient as one column-sum launch) against the
+    reference's TWO netR_FC calls evaluated in fp64: outputs, both running-statistics updates, every parameter gradient and
+    the gradient of x_pre (view-max routing included).  M % 32 == 0 in all cases, so the fused path is the one that runs; the
+    clip segment has 4 .. 32 rows, the case the GEMM-epilogue fp32 statistics could not serve.  The single-segment kernels
+    (FACL_FC_FUSED=0 semantics, forced here through the module switch) must give the same numbers."""
+    from facl_amd import tail
+    from facl_amd.cn3d_model_conbag import _Affine, _BatchNormState
+    torch.manual_seed(G * 1000 + B)
+    M = G * B
+    x_pre = (torch.randn(M, Cin, device=DEV) * 2.0).abs()              # post-ReLU-like features
+    lin1, lin2, bn = _Affine((C, Cin), Cin).to(DEV), _Affine((dim, C), C).to(DEV), _BatchNormState(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, device=DEV) * 0.5 + 1.0)
+        bn.weight[0] = -0.7                                            # a negative gamma
+        bn.bias.copy_(torch.randn(C, device=DEV) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, device=DEV))
+        bn.running_var.copy_(torch.rand(C, device=DEV) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    gout = torch.randn(M + B, dim, device=DEV)
+
+    def run(fused):
+        bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+        for p in (*lin1.parameters(), *lin2.parameters(), *bn.parameters()):
+            p.grad = None
+        xa = x_pre.clone().requires_grad_(True)
+        prev, tail._FC_FUSED = tail._FC_FUSED, fused
+        try:
+            out = tail.fc_head(xa, G, lin1, bn, lin2, True)
+            (out * gout).sum().backward()
+        finally:
+            tail._FC_FUSED = prev
+        return (out.detach(), xa.grad, lin1.weight.grad, bn.weight.grad, bn.bias.grad, lin2.weight.grad, lin2.bias.grad,
+                bn.running_mean.clone(), bn.running_var.clone())
+
+    steps0 = bn.steps
+    got = run(True)
+    assert bn.steps == steps0 + 2                                      # two BatchNorm calls counted
+    old = run(False)
+    # fp64 truth
+    d = lambda t: t.detach().double()
+    xr = d(x_pre).requires_grad_(True)
+    W1, b1, W2, b2 = (d(lin1.weight).requires_grad_(True), d(lin1.bias), d(lin2.weight).requires_grad_(True), d(lin2.bias).requires_grad_(True))
+    ga, be = d(bn.weight).requires_grad_(True), d(bn.bias).requires_grad_(True)
+    ref, rm, rv = _fc_head_reference_fp64(xr, G, W1, b1, ga, be, W2, b2, d(rm0), d(rv0))
+    (ref * d(gout)).sum().backward()
+    truth = (ref.detach(), xr.grad, W1.grad, ga.grad, be.grad, W2.grad, b2.grad, rm, rv)
+    names = ("out", "dx_pre", "dW1", "dgamma", "dbeta", "dW2", "db2", "running_mean", "running_var")
+    for name, g_, o_, t_ in zip(names, got, old, truth):
+        scale = float(t_.abs().max()) + 1e-30
+        e_new, e_old = float((g_.double() - t_).abs().max()) / scale, float((o_.double() - t_).abs().max()) / scale
+        assert e_new < 2e-5, (name, e_new)                             # measured 1e-7 .. 4e-6 (bf16x6 GEMMs, fp64 statistics)
+        assert e_new < 4 * e_old + 1e-6, (name, e_new, e_old)          # and no worse than the single-segment kernels
+
+
+def test_col_sums_viewmax_stack_and_loss_sum_entries():
+    """The three small entries of the FC head / loss glue through the C ABI: facl_col_sums == x.sum(0) (fp64 accumulation),
+    facl_viewmax_stack == [x ; max over views] with the first view winning ties, facl_contrast_pair_sum's fp32 triple ==
+    (float(loss_c), float(loss_circle), float(loss_circle) + float(loss_c)) of facl_contrast_pair on the same inputs."""
+    from facl_amd import _lib
+    from facl_amd.sa_mlp import _Workspace
+    lib = _lib.load_library()
+    torch.manual_seed(3)
+    x = torch.randn(800, 512, device=DEV)
+    out = torch.empty(512, device=DEV)
+    _lib.check(lib.facl_col_sums(_lib.ptr(x), 800, 512, _lib.ptr(out), _lib.stream()), "facl_col_sums")
+    assert float((out.double() - x.double().sum(0)).abs().max()) < 1e-5
+    G, B, C = 6, 5, 16
+    xv = torch.randint(0, 3, (G * B, C), device=DEV).float()           # ties on purpose
+    h = torch.empty(G * B + B, C, device=DEV)
+    arg = torch.empty(B, C, dtype=torch.int32, device=DEV)
+    _lib.check(lib.facl_viewmax_stack(_lib.ptr(xv), G, B, C, _lib.ptr(h), _lib.ptr(arg), _lib.stream()), "facl_viewmax_stack")
+    ref = xv.view(G, B, C).max(dim=0).values
+    first = (xv.view(G, B, C) == ref.unsqueeze(0)).float().argmax(dim=0)
+    assert torch.equal(h[:G * B], xv) and torch.equal(h[G * B:], ref) and torch.equal(arg.long(), first)
+    # loss triple
+    Bk = B
+    J = G * Bk
+    sim = torch.randn((G + 1) * B, J, device=DEV)
+    order = torch.randperm(G, device=DEV)
+    ws = _Workspace.get(torch.device(DEV))
+    d0, d1 = torch.empty_like(sim), torch.empty_like(sim)
+    l0, l1 = torch.empty(2, dtype=torch.float64, device=DEV), torch.empty(2, dtype=torch.float64, device=DEV)
+    l32 = torch.empty(3, device=DEV)
+    _lib.check(lib.facl_contrast_pair(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), 0, _lib.ptr(d0), _lib.ptr(l0), _lib.ptr(ws), _lib.stream()), "pair")
+    _lib.check(lib.facl_contrast_pair_sum(_lib.ptr(sim), G, B, Bk, J, _lib.ptr(order), 0, _lib.ptr(d1), _lib.ptr(l1), _lib.ptr(l32),
+                                          _lib.ptr(ws), _lib.stream()), "pair_sum")
+    assert torch.equal(d0, d1)
+    assert float((l0 - l1).abs().max()) < 1e-12 * float(l0.abs().max())
+    c, o = l1[0].float(), l1[1].float()
+    assert torch.equal(l32, torch.stack((c, o, o + c)))

@@ -49,7 +49,7 @@ def main():
                              "--warmup 1 --no-cpu-baseline --graph 0`), FETCH doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                              f"requests at 64 B); see {tag}_pmc_traffic.md.",
                  "shape": {"B": 32, "T": 24, "N": 2048, "D": 3}, "build": tag,
-                 "k_sa_bwd1": pick("k_sa_bwd1"), "k_sa_bwd2_sb": pick("k_sa_bwd2_sb"), "k_sa_bwd_w3": pick("k_sa_bwd_w3"),
+                 "k_sa_bwd1": pick("k_sa_bwd1"), "k_sa_bwd2_sb": pick("k_sa_bwd2_sb"), "k_sa_bwd_w3": pick("k_sa_bwd_w3("), "k_sa_bwd_w3p": pick("k_sa_bwd_w3p"),
                  "k_sa_fwd3_sb": pick("k_sa_fwd3_sb"), "k_sa_fwd2_sb": pick("k_sa_fwd2_sb"), "k_group": pick("k_group"),
                  "k_gemm_rs fwd 49152x512x1024": pick("k_gemm_rs<true, true, false"),
                  "k_gemm_rs fwd 49152x256x512": pick("k_gemm_rs<true, false, false"),

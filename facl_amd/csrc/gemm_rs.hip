@@ -549,11 +549,21 @@ struct WgArgs {
 
 // H3: fp16x3 arithmetic (common.h): dy scaled by the power of two that puts max|dy| in [2^13, 2^14), f(y) by 2^4, two fp16
 // planes each, three products; the accumulators are rescaled (exactly) before the slices are written.
-template <bool PRO, bool H3>
+// WIDE (round 4, late): the dy^T fragments (lane = channel, 8 consecutive rows) used to be 32 global_load_dword per wave and stage,
+// 256 B each -- the CU's address path, not the MFMA pipe, paced the kernel (ablation: -33 % without them; 8 waves x 40 vector-memory
+// instructions of 64 addresses per stage against 2 x 1536 MFMA cycles per SIMD).  Now a wave fetches its 32 rows x 64 channels as
+// 8 global_load_dwordx4 (1 KiB each: four whole 256-B row pieces), parks them in a per-wave LDS image [row][68] (272-B rows:
+// 16-B aligned for the b128 writes, and rows 8 apart sit 32 banks apart, so the two lane halves of a fragment read never
+// collide) and reads the fragments back with ds_read_b32: 16 vector-memory instructions per wave and stage instead of 40.
+constexpr int WG_TP = 68;
+template <bool PRO, bool H3, bool WIDE = false>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
     constexpr int NPL = H3 ? 2 : 3;
-    __shared__ __attribute__((aligned(16))) uint4 bring[2][2 * 4 * NPL * 64];      // 2 stages x (2 k-steps x 4 k-tiles x planes x 64 lanes): 48 / 32 KiB
-    __shared__ __attribute__((aligned(16))) float stg_all[WG_WAVES][32 * 32];       // epilogue staging, 4 KiB per wave
+    constexpr int BRING_U4 = 2 * (2 * 4 * NPL * 64);                                // 2 stages x (2 k-steps x 4 k-tiles x planes x 64 lanes): 48 / 32 KiB
+    constexpr int WSTG_F = WIDE ? 32 * WG_TP : 32 * 32;                             // per-wave staging: dy image (WIDE) / epilogue tile
+    extern __shared__ __attribute__((aligned(16))) char wg_lds[];
+    uint4 (*bring)[2 * 4 * NPL * 64] = reinterpret_cast<uint4 (*)[2 * 4 * NPL * 64]>(wg_lds);
+    float* const stg_base = reinterpret_cast<float*>(wg_lds + BRING_U4 * 16);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: the K/128 workgroups that read the same dy rows (same n block, same row slice) are consecutive
@@ -621,6 +631,34 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
             }
     };
 
+    // WIDE: the same rows as 8 x 16 B per lane (instruction i: rows 4i + (lane >> 4), channels 4 (lane & 15) .. + 3), and the
+    // trip through the wave's LDS image
+    float* const dimg = stg_base + wave * WSTG_F;
+    const float* dsrc4 = g.dy + n0 + 4 * (lane & 15);
+    auto load_raw = [&](int s, float4 (&r)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = p0 + 32 * s + 4 * i + (lane >> 4);
+            const bool in = p < p1;
+            const float4 v = *reinterpret_cast<const float4*>(dsrc4 + (size_t)(in ? p : p1 - 1) * g.N);
+            r[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto raw_to_frags = [&](const float4 (&r)[8], float (&f)[2][2][8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<float4*>(dimg + (4 * i + (lane >> 4)) * WG_TP + 4 * (lane & 15)) = r[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // same-wave hand-off (lanes swap roles)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) f[ks][nt][e] = dimg[(16 * ks + 8 * h + e) * WG_TP + 32 * nt + q];
+        // (no wait here: the reads land under the MFMAs that follow; the image is rewritten a whole stage later, and a wave's
+        // DS operations execute in order)
+    };
+
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -632,18 +670,22 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
     constexpr int HA[3] = FACL_H3_PA, HB[3] = FACL_H3_PB;
 
     float rb[8], ra[2][2][8];
+    float4 raw[8];
     load_b(0, rb);
-    load_a(0, ra);
+    if (WIDE) { load_raw(0, raw); raw_to_frags(raw, ra); }
+    else load_a(0, ra);
     store_b(0, rb);
     if (nst > 1) load_b(1, rb);
     __syncthreads();
     for (int s = 0; s < nst; ++s) {
         float ran[2][2][8];
-        if (s + 1 < nst) load_a(s + 1, ran);                                       // next stage's dy^T fragments in flight
+        if (s + 1 < nst) {                                                         // next stage's dy^T rows / fragments in flight
+            if (WIDE) load_raw(s + 1, raw);
+            else load_a(s + 1, ran);
+        }
         const uint4* bs = &bring[s & 1][lane];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][NPL];
+        // k-step ks: split the wave's two dy^T fragments into planes, then 4 k tiles x (3 | 6) products x 2 n tiles
+        auto split_a = [&](int ks, bf16x8 (&af)[2][NPL]) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 unsigned hi[4], mi[4], lo[4];
@@ -658,6 +700,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
                 af[nt][0] = as_bf16x8(hi[0], hi[1], hi[2], hi[3]);
                 af[nt][1] = as_bf16x8(mi[0], mi[1], mi[2], mi[3]);
             }
+        };
+        auto mfma_ks = [&](int ks, const bf16x8 (&af)[2][NPL]) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 bf16x8 bf[NPL];
@@ -677,22 +721,34 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad_rs(WgArgs g) {
                     }
                 }
             }
+        };
+        {
+            bf16x8 af0[2][NPL], af1[2][NPL];
+            split_a(0, af0);
+            mfma_ks(0, af0);
+            split_a(1, af1);
+            // WIDE: every fragment of this stage is in planes now -> the next stage's rows go through the LDS image HERE, so
+            // that the round trip runs under the second k-step's 24 MFMAs instead of in front of the barrier
+            if (WIDE && s + 1 < nst) raw_to_frags(raw, ra);
+            mfma_ks(1, af1);
         }
         if (s + 1 < nst) {
             store_b(s + 1, rb);                                                    // into the buffer stage s-1 used: all waves left it at the last barrier
             if (s + 2 < nst) load_b(s + 2, rb);
+            if (!WIDE) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ra[ks][nt][e] = ran[ks][nt][e];
+                        for (int e = 0; e < 8; ++e) ra[ks][nt][e] = ran[ks][nt][e];
+            }
         }
         __syncthreads();                                                           // stage s+1 is written, stage s is read by everyone
     }
 
     // ---- epilogue: lane = column k0 + 32 kt + q, register r = row n0 + 32 nt + rowmap(r, h); through the per-wave LDS image
-    float* const stg = stg_all[wave];
+    float* const stg = stg_base + wave * WSTG_F;
     float* const out = g.slices + (size_t)bz * g.N * g.K;
     const int srow = lane >> 3, schunk = lane & 7;
 #pragma unroll
@@ -963,10 +1019,21 @@ extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, in
     WgArgs g{dy, y, (int)M, N, K, pscale, pshift, slices, rps, amax, amax_b};
     dim3 grid(K / 128, N / 512, nz);
     const dim3 blk(64 * WG_WAVES);
-    if (pscale && amax) hipLaunchKernelGGL((k_wgrad_rs<true, true>), grid, blk, 0, st, g);
-    else if (pscale) hipLaunchKernelGGL((k_wgrad_rs<true, false>), grid, blk, 0, st, g);
-    else if (amax) hipLaunchKernelGGL((k_wgrad_rs<false, true>), grid, blk, 0, st, g);
-    else hipLaunchKernelGGL((k_wgrad_rs<false, false>), grid, blk, 0, st, g);
+    // dynamic LDS: plane ring (48 / 32 KiB) + per-wave staging (WIDE: the dy image, 8.5 KiB per wave; else the 4-KiB epilogue tile)
+    static const int wide = getenv("FACL_WGRAD_WIDE") ? atoi(getenv("FACL_WGRAD_WIDE")) : 1;      // 0: dword fragment loads (A/B)
+    const int lds3 = 2 * (2 * 4 * 3 * 64) * 16, lds2 = 2 * (2 * 4 * 2 * 64) * 16;
+    const int stg_n = WG_WAVES * 32 * 32 * 4, stg_w = WG_WAVES * 32 * WG_TP * 4;
+    static bool attr_done[64] = {};
+    const void* fns[6] = {(const void*)k_wgrad_rs<true, true>, (const void*)k_wgrad_rs<true, false>, (const void*)k_wgrad_rs<false, true>,
+                          (const void*)k_wgrad_rs<false, false>, (const void*)k_wgrad_rs<true, true, true>,
+                          (const void*)k_wgrad_rs<false, true, true>};
+    if (int rc0 = facl_set_dynamic_lds(attr_done, fns, 6, lds3 + stg_w)) return rc0;
+    if (pscale && amax && wide) hipLaunchKernelGGL((k_wgrad_rs<true, true, true>), grid, blk, lds2 + stg_w, st, g);
+    else if (amax && wide) hipLaunchKernelGGL((k_wgrad_rs<false, true, true>), grid, blk, lds2 + stg_w, st, g);
+    else if (pscale && amax) hipLaunchKernelGGL((k_wgrad_rs<true, true>), grid, blk, lds2 + stg_n, st, g);
+    else if (pscale) hipLaunchKernelGGL((k_wgrad_rs<true, false>), grid, blk, lds3 + stg_n, st, g);
+    else if (amax) hipLaunchKernelGGL((k_wgrad_rs<false, true>), grid, blk, lds2 + stg_n, st, g);
+    else hipLaunchKernelGGL((k_wgrad_rs<false, false>), grid, blk, lds3 + stg_n, st, g);
     int rc = facl_launch_status();
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;

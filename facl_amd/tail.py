@@ -373,8 +373,7 @@ class _FCHead(torch.autograd.Function):
                                             _lib.stream()), "facl_fc_bn_apply")
             bn.count_batch()
             bn.count_batch()
-            bncs = [bnc2[0], bnc2[1]]
-            ctx.bnc2 = bnc2
+            bncs = [bnc2]                                        # one (2, 5, C) tensor: both segments' constants
         else:
             y, _ = gemm_fwd(h, W1, b1, prec=ctx.prec)
             a = _lib.empty_like(y)
@@ -413,7 +412,9 @@ class _FCHead(torch.autograd.Function):
         if not ctx.training:
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         lib = _lib.load_library()
-        h, W1, y, a, W2, arg, bnc_a, bnc_b = ctx.saved_tensors
+        h, W1, y, a, W2, arg, *bncs = ctx.saved_tensors
+        bnc2 = bncs[0] if ctx.fused else None
+        bnc_a, bnc_b = (bnc2[0], bnc2[1]) if ctx.fused else bncs
         ws = _Workspace.get(y.device)
         R, C = y.shape
         M = ctx.segs[0][1]
@@ -433,7 +434,6 @@ class _FCHead(torch.autograd.Function):
         dact = gemm_dgrad(dout, W2, prec=bp)
         dy = _lib.empty_like(y)
         if ctx.fused:
-            bnc2 = ctx.bnc2
             sums2 = sums2_g = None
             if ctx.reduce_fn is not None:
                 sums2 = _lib.empty((2, C, 2), dtype=torch.float64, device=y.device)

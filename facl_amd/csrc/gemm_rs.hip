@@ -35,6 +35,9 @@ constexpr int RS_ASLOT = 32 * 128;                // bytes of one stage (32 k) o
 constexpr int RS_LDS_W = 2 * RS_WSLOT;            // 48 KiB: k-step j in slot j & 1
 constexpr int RS_LDS_A = RS_WAVES * RS_ASLOT;     // 16 KiB (one stage slot per wave)
 constexpr int RS_KMAX = 1024;                     // longest contraction
+#ifndef RS_H3_AHEAD2
+#define RS_H3_AHEAD2 0                             // 1: fp16x3 kernels request their B fragments TWO MFMA groups ahead (round 4: measured equal / slower)
+#endif
 constexpr int RS_KPRO = 512;                      // longest contraction WITH a prologue: tables scale[K] | shift[K], 4 KiB
 constexpr int RS_LDS = RS_LDS_W + RS_LDS_A + 2 * RS_KPRO * 4;     // 68 KiB
 
@@ -315,6 +318,28 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
     auto mfma_step = [&](int j, const unsigned (&pk)[12], auto&& mid_a, auto&& mid_b) {
         const uint4* ws = reinterpret_cast<const uint4*>(wring + (j & 1) * RS_WSLOT) + lane;
         const bf16x8 P[3] = {frag(pk, 0), frag(pk, 1), frag(pk, H3 ? 1 : 2)};
+        if (H3 && RS_H3_AHEAD2) {
+            // (experiment, off: an fp16x3 group is THREE MFMAs (96 cycles), shorter than an LDS round trip under load; here the
+            // fragments of a column tile are requested TWO groups ahead (three rotating register sets), as far ahead in cycles as
+            // the six-MFMA groups of bf16x6 were with one.  Same box, bit-identical: forward 49152x512x1024 0.197 vs 0.198 ms,
+            // dgrad 1024->512 0.201 vs 0.185: the B-fragment latency is not what these kernels wait for.  gpurun_out/r5m_ab.log)
+            bf16x8 bq[3][3];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) { bq[0][p] = __builtin_bit_cast(bf16x8, ws[p * 64]); bq[1][p] = __builtin_bit_cast(bf16x8, ws[(NPL + p) * 64]); }
+#pragma unroll
+            for (int ct = 0; ct < RS_CT; ++ct) {
+                if (ct + 2 < RS_CT) {
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) bq[(ct + 2) % 3][p] = __builtin_bit_cast(bf16x8, ws[((ct + 2) * NPL + p) * 64]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ct == 2) mid_a();
+                if (ct == 4) mid_b();
+                mfma_group(acc[ct], P, bq[ct % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         bf16x8 b0[3], b1[3];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) b0[p] = __builtin_bit_cast(bf16x8, ws[p * 64]);

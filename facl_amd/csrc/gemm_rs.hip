@@ -35,6 +35,9 @@ constexpr int RS_ASLOT = 32 * 128;                // bytes of one stage (32 k) o
 constexpr int RS_LDS_W = 2 * RS_WSLOT;            // 48 KiB: k-step j in slot j & 1
 constexpr int RS_LDS_A = RS_WAVES * RS_ASLOT;     // 16 KiB (one stage slot per wave)
 constexpr int RS_KMAX = 1024;                     // longest contraction
+#ifndef RS_PREP_IN_ODD
+#define RS_PREP_IN_ODD 1                           // next stage's fragment read + first planes inside the odd k-step's MFMA stream (0: behind the barrier)
+#endif
 #ifndef RS_H3_AHEAD2
 #define RS_H3_AHEAD2 0                             // 1: fp16x3 kernels request their B fragments TWO MFMA groups ahead (round 4: measured equal / slower)
 #endif
@@ -388,6 +391,20 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issueW(j + 2);
+        if (RS_PREP_IN_ODD) {
+            // The next stage's activation fragments and first planes are prepared INSIDE this k-step's MFMA stream (its hooks were
+            // empty): in flight here are A(j/2+1) [4 pieces, issued during the even k-step] and then W(j+2) [WPP pieces], so
+            // vmcnt(WPP) means the activations have landed; the slot is this wave's own (no barrier), `raw` and P0 are dead since
+            // the even k-step.  In-kernel stamps (s_memtime, scratch/exp_rs) had put this chain -- LDS round trip + 40 VALU behind
+            // the barrier -- at 15 % of the loop.
+            mfma_step(j + 1, P1,
+                      [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WPP) : "memory"); read_stage(raw); },
+                      [&]() { planes_half(j + 2, raw[0], P0, 0); planes_half(j + 2, raw[1], P0, 1); });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issueW(j + 3);
+            continue;
+        }
         mfma_step(j + 1, P1, nop, nop);
         // -- top of the next stage: W(j+2) and A(j/2+1) have landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -442,31 +459,50 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
     float* const wbest = wstat + 512;                                            // SEG, odd waves: (max, arg): 2 KiB
     float* const ystg = wstat + 512;                                             // BST: y tile image, 4 KiB
     const int srow = lane >> 3, schunk = lane & 7;                                // row-major side: 8 lanes per 128-B row
+    // EVERY global load of the epilogue is issued before the first store (the per-column constants of all eight tiles here, the
+    // BatchNorm-backward variant's y tile one tile ahead): a load behind a store waits for it -- vmcnt counts stores, in order --
+    // and the per-tile `bias[n]` / `wse[tile]` loads used to put a full HBM store round trip between consecutive tiles: in-kernel
+    // stamps (s_memtime, scratch/exp_rs) showed 17k cycles for the eight tiles of a workgroup, 20 % of its life.
+    float biasv[RS_CT], sgv[RS_CT], unsv[RS_CT];
 #pragma unroll
     for (int ct = 0; ct < RS_CT; ++ct) {
         const int n = 256 * cb + 32 * ct + q;
-        const float bias = g.bias ? g.bias[n] : 0.f;
-        const float sg = SEG ? sgn_of(g.sgn[n]) : 1.f;
-        const float uns = H3 ? h3_unscale(seA, g.wse[RS_CT * cb + ct]) : 1.f;       // this column tile's 1 / (sA sW): exact
+        biasv[ct] = g.bias ? g.bias[n] : 0.f;
+        sgv[ct] = SEG ? sgn_of(g.sgn[n]) : 1.f;
+        unsv[ct] = H3 ? h3_unscale(seA, g.wse[RS_CT * cb + ct]) : 1.f;             // this column tile's 1 / (sA sW): exact
+    }
+    // BST: the layer's raw output under a tile + its BatchNorm constants, fetched one tile ahead into NAMED registers (arrays
+    // written through a helper ended up in scratch)
+    struct YTile { float4 y0, y1, y2, y3; float mean, inv, sc, sh; };
+    auto fetch_y = [&](int ct) -> YTile {
+        YTile t;
+        const int n_ = 256 * cb + 32 * ct + q;
+        t.mean = g.bbnc[n_]; t.inv = g.bbnc[g.N + n_]; t.sc = g.bbnc[2 * g.N + n_]; t.sh = g.bbnc[3 * g.N + n_];
+        const float* base = g.by + 256 * cb + 32 * ct + 4 * schunk;
+        int r0_ = row0 + srow, r1_ = row0 + 8 + srow, r2_ = row0 + 16 + srow, r3_ = row0 + 24 + srow;
+        r0_ = r0_ < g.M ? r0_ : g.M - 1; r1_ = r1_ < g.M ? r1_ : g.M - 1; r2_ = r2_ < g.M ? r2_ : g.M - 1; r3_ = r3_ < g.M ? r3_ : g.M - 1;
+        t.y0 = *reinterpret_cast<const float4*>(base + (size_t)r0_ * g.N);
+        t.y1 = *reinterpret_cast<const float4*>(base + (size_t)r1_ * g.N);
+        t.y2 = *reinterpret_cast<const float4*>(base + (size_t)r2_ * g.N);
+        t.y3 = *reinterpret_cast<const float4*>(base + (size_t)r3_ * g.N);
+        return t;
+    };
+    YTile ycur = {}, ynxt = {};
+    if (BST) ycur = fetch_y(0);
+#pragma unroll
+    for (int ct = 0; ct < RS_CT; ++ct) {
+        const float bias = biasv[ct], sg = sgv[ct], uns = unsv[ct];
         float s = 0.f, sq = 0.f, best = 0.f;
         int bp = 0;
         float bmean = 0.f, binv = 0.f, bsc = 0.f, bsh = 0.f;
-        if (BST) {                                                     // the layer's raw output under this tile
-            bmean = g.bbnc[n]; binv = g.bbnc[g.N + n]; bsc = g.bbnc[2 * g.N + n]; bsh = g.bbnc[3 * g.N + n];
-            float4 yl[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = 8 * t + srow;
-                int gr = row0 + row;
-                gr = gr < g.M ? gr : g.M - 1;
-                yl[t] = *reinterpret_cast<const float4*>(g.by + (size_t)gr * g.N + 256 * cb + 32 * ct + 4 * schunk);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = 8 * t + srow;
-                *reinterpret_cast<float4*>(ystg + row * 32 + ((schunk ^ ((row >> 1) & 7)) << 2)) = yl[t];
-            }
+        if (BST) {
+            bmean = ycur.mean; binv = ycur.inv; bsc = ycur.sc; bsh = ycur.sh;
+            *reinterpret_cast<float4*>(ystg + (srow) * 32 + ((schunk ^ ((srow >> 1) & 7)) << 2)) = ycur.y0;
+            *reinterpret_cast<float4*>(ystg + (8 + srow) * 32 + ((schunk ^ (((8 + srow) >> 1) & 7)) << 2)) = ycur.y1;
+            *reinterpret_cast<float4*>(ystg + (16 + srow) * 32 + ((schunk ^ (((16 + srow) >> 1) & 7)) << 2)) = ycur.y2;
+            *reinterpret_cast<float4*>(ystg + (24 + srow) * 32 + ((schunk ^ (((24 + srow) >> 1) & 7)) << 2)) = ycur.y3;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ct + 1 < RS_CT) ynxt = fetch_y(ct + 1);                // ahead of this tile's stores
         }
         float q4[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -518,6 +554,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
                 acc[ct][0] = best; acc[ct][1] = __int_as_float(bp);                    // parked until the partner has written
             }
         }
+        if (BST) ycur = ynxt;
     }
     if (!g.part && !SEG) return;
     __syncthreads();

@@ -231,10 +231,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
     if (H3) seA = h3_se_wide_of(g.amax);                                // the wide clamp: A is a gradient in the dgrad form
     const float sA = pow2_biased(seA);
 
-    if (PRO) {
-        for (int i = tid; i < g.K; i += 64 * WV) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
-        __syncthreads();
-    }
+    // (PRO: the prologue tables are filled BEHIND the first DMAs -- one cold memory round trip instead of two)
 
     // ---- DMA issue helpers (wave-uniform control flow; VM-counter bookkeeping in the pipeline comment below)
     // this wave's share of the k-step's column tiles: WPP consecutive 1-KiB pieces
@@ -373,10 +370,13 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
     // also lands A(j/2), needed now.  The workgroup barrier behind the wait makes every wave's pieces of W(j) visible and
     // proves that all waves have left k-step j-1, whose slot the next issue overwrites.
     issueA(0); issueW(0);
+    if (PRO) {
+        for (int i = tid; i < g.K; i += 64 * WV) { tab[i] = g.pscale[i]; tab[RS_KPRO + i] = g.pshift[i]; }
+    }
     unsigned P0[12], P1[12];
     float4 raw[4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();                                                   // DMA pieces landed, tables written (LDS stores drained)
     read_stage(raw);
     planes_half(0, raw[0], P0, 0);
     planes_half(0, raw[1], P0, 1);

@@ -108,8 +108,14 @@ SIGNATURES = {
     "facl_col_sums": [c_p, c_l, c_i, c_p, c_p],
     "facl_contrast_pair_sum": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_wgrad_acc": [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_p],
+    "facl_mailbox_bytes": [c_i, c_i],
+    "facl_mailbox_alloc": [c_l, c_p, c_p],
+    "facl_mailbox_open": [c_p, c_p],
+    "facl_mailbox_close": [c_p],
+    "facl_mailbox_free": [c_p],
+    "facl_mailbox_allreduce": [c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p],
 }
-RESTYPE_I64 = {"facl_ws_bytes", "facl_gemm_rs_planes_bytes"}
+RESTYPE_I64 = {"facl_ws_bytes", "facl_gemm_rs_planes_bytes", "facl_mailbox_bytes"}
 
 
 def lib_path():

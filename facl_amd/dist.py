@@ -184,15 +184,26 @@ def collective(fn):
 
 
 def make_bn_reduce_fn(group=None):
-    """In-place SUM all-reduce of an fp64 statistics buffer (SyncBN hook of the BN passes)."""
+    """In-place SUM all-reduce of an fp64 statistics buffer (SyncBN hook of the BN passes).
+
+    OPT-IN ``FACL_ONESHOT_SYNCBN=1``: the reduction is ONE kernel launch on the current stream through peer-mapped mailboxes
+    (facl_amd/mailbox.py, csrc/mailbox.hip) instead of a collective of the process group: no graph cut, no RCCL latency; sums are
+    added in rank order (bit-identical on every rank).  Rehearsed with processes sharing one GPU only -- never the default."""
     if not is_distributed():
         return None
+    oneshot = None
+    if os.environ.get("FACL_ONESHOT_SYNCBN", "0") not in ("", "0"):
+        from .mailbox import OneShotAllReduce
+        oneshot = OneShotAllReduce(group, n_max=4608)        # the largest SyncBN buffer of the step: B2_V = 4608 doubles
 
     def reduce_fn(t):
+        if oneshot is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= oneshot.n_max:
+            return oneshot(t)
         collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
         return t
 
     reduce_fn.world_size = dist.get_world_size(group)        # equal shards: global counts = local * world_size
+    reduce_fn.oneshot = oneshot
     return reduce_fn
 
 

@@ -430,6 +430,23 @@ int facl_scale_rows2(const float* src, float* dst, int64_t R1, int64_t R, int J,
 int facl_normalize_map(const float* x, int64_t M, int C, const float* Wm, int K, float* x_nor, float* code,
                        void* stream);
 
+/* ---- OPT-IN one-shot all-reduce of a small fp64 buffer through peer-mapped mailboxes (csrc/mailbox.hip; FACL_ONESHOT_SYNCBN=1):
+ * the 14 SyncBN reductions of the data-parallel step (0.1-16 KB each: the statistics the reference's single-process BatchNorm
+ * layers take over the whole batch, cn3d_model_conbag.py:46-84) as ONE capturable kernel launch per rank and call instead of a
+ * latency-bound RCCL collective.  Every rank allocates a mailbox (facl_mailbox_alloc: device memory + its 64-byte IPC handle),
+ * opens every peer's (facl_mailbox_open), and calls facl_mailbox_allreduce in the same order: out = sum over the R ranks of
+ * their `in`, added in rank order (bit-identical on every rank).  boxes: DEVICE array of R mailbox pointers, own at [rank]; seq: a
+ * device uint64 that starts at 0 (the kernel advances it: a replayed graph posts fresh sequence numbers); err: device word
+ * raised -- and the output poisoned with NaN -- when a peer does not post within 2 s (the wait never hangs the GPU).
+ * Rehearsed with 2 / 4 processes on one GPU; cross-device visibility over xGMI is untested: never the default. */
+int64_t facl_mailbox_bytes(int R, int n_max);
+int facl_mailbox_alloc(int64_t bytes, void** ptr, void* handle64);
+int facl_mailbox_open(const void* handle64, void** ptr);
+int facl_mailbox_close(void* ptr);
+int facl_mailbox_free(void* ptr);
+int facl_mailbox_allreduce(const double* in, double* out, int n, int n_max, void* const* boxes, int rank, int R, uint64_t* seq,
+                           uint32_t* err, void* stream);
+
 /* ---- optimizer step (cn3d_train_motion_GL.py:180,:332: Adam, betas (0.5, 0.999), eps 1e-6, no weight decay) ------------
  * facl_adam_prep: step[0] += 1 (device float), consts = (lr[0] / (1 - b1^t), 1 / sqrt(1 - b2^t)) -- lr and the step
  * counter live on the device so that a captured HIP graph advances them by itself.

@@ -42,10 +42,11 @@ def _run_step(clip, G, rank, world):
     return float(loss.item()), grads, bufs
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, extra_env=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       FACL_DIST_BACKEND="gloo")
+    os.environ.update(extra_env or {})
     import torch.distributed as dist
     from facl_amd import dist as fdist
     torch.cuda.set_device(0)
@@ -59,11 +60,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_single_process_global_batch():
+@pytest.mark.parametrize("oneshot", [False, True])
+def test_two_ranks_equal_single_process_global_batch(oneshot):
+    """oneshot: the SyncBN reductions go through the OPT-IN peer-mailbox kernel (FACL_ONESHOT_SYNCBN=1, csrc/mailbox.hip: both
+    ranks open each other's IPC handle on the one GPU) instead of the process group's all-reduce; same bounds."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + (7 if oneshot else 0)
+    env = {"FACL_ONESHOT_SYNCBN": "1"} if oneshot else {"FACL_ONESHOT_SYNCBN": "0"}
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, env)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
@@ -389,3 +394,71 @@ def test_optin_full_graph_capture_of_the_data_parallel_step():
     print("eager", eager, "full graph", graph)
     for a, b in zip(eager, graph):
         assert abs(a - b) <= 1e-5 * abs(a)
+
+
+def _worker_mailbox(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from facl_amd.mailbox import OneShotAllReduce
+    ar = OneShotAllReduce(None, n_max=4608)
+
+    def vals(r, it, n):                                     # magnitudes over five decades: the ORDER of the additions matters
+        g = torch.Generator().manual_seed(1000 * it + r)
+        return torch.randn(n, generator=g, dtype=torch.float64) * (10.0 ** (it % 5 - 2))
+
+    def expect(it, n):
+        ref = torch.zeros(n, dtype=torch.float64)
+        for r in range(world):
+            ref = ref + vals(r, it, n)                      # rank order
+        return ref
+    ok = True
+    for it, n in enumerate([128, 2048, 4608, 1, 512] * 6):  # 30 calls: both slot parities, every size class
+        t = vals(rank, it, n).cuda()
+        ar(t)
+        ok = ok and torch.equal(t.cpu(), expect(it, n))
+    # the same kernel inside a captured graph, replayed with fresh inputs: the sequence number lives on the device
+    a, b = (torch.zeros(n, dtype=torch.float64, device="cuda") for n in (128, 2048))
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        ar(a); ar(b)
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize(); dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ar(a); ar(b)
+    for rep in range(4):
+        for j, t in enumerate((a, b)):
+            t.copy_(vals(rank, 100 + 10 * rep + j, t.numel()).cuda())
+        torch.cuda.synchronize(); dist.barrier()
+        g.replay()
+        torch.cuda.synchronize()
+        for j, t in enumerate((a, b)):
+            ok = ok and torch.equal(t.cpu(), expect(100 + 10 * rep + j, t.numel()))
+    ar.check()
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_mailbox_allreduce_equals_rank_ordered_sum(world):
+    """facl_mailbox_allreduce with `world` processes sharing the one GPU, each opening the others' IPC
+    handles exactly as peers on other devices would: 30 eager calls (sizes 1 .. 4608 doubles, values over five decades) and a
+    captured graph replayed four times must equal the sum in RANK ORDER bit for bit on every rank; no time-out was raised.
+    What this cannot show is cross-device visibility over xGMI: the path stays opt-in."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker_mailbox, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)], res
+    assert all(p.exitcode == 0 for p in procs)

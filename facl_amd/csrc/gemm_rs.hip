@@ -62,6 +62,8 @@ struct RsArgs {
     const unsigned* amax;                         // h3 only: bits of (a bound of) max|A| in FACL_AMAX_SLOTS slots -> the
                                                   // power-of-two scale of A (activations: their bound, gradients: max|dy|)
     const int* wse;                               // h3 only: biased exponent of the weight scale per 32-column tile (k_rs_planes)
+    int phase_ticks;                              // experiment (FACL_RS_PHASE): first-round workgroups in the CU's second slot start this many 100-MHz ticks late
+    int first_round;                              // number of workgroups resident at launch (2 per CU)
 };
 
 
@@ -215,6 +217,17 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
     constexpr int NPL = H3 ? 2 : 3;                                     // planes per fragment (fp16x3 / bf16x6, common.h)
     constexpr int WPP = RS_CT * NPL / WV;                         // 1-KiB weight pieces a wave issues per k-step
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (g.phase_ticks > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < g.first_round) {
+        // Phase-offset experiment: the two workgroups of a CU start together and take the same time, so they stay in phase for
+        // the whole launch -- both in the main loop (MFMA pipe shared) or both draining their output (pipe idle).  The one in
+        // the CU's second thread-group slot (HW_ID.TG_ID) waits here once; the offset then persists round after round.
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw >> 16) & 1u) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.phase_ticks) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* const wring = lds;
@@ -867,7 +880,16 @@ int rs_waves(int h3) {
     return (h3 && w8) ? 8 : RS_WAVES;
 }
 
-int rs_launch(const RsArgs& g, hipStream_t st) {
+int rs_launch(const RsArgs& g0, hipStream_t st) {
+    RsArgs g = g0;
+    {   // Phase offset of the CU's second workgroup slot (see the kernel): ticks x k-steps + 500 of the 100-MHz counter, i.e. about
+        // half a workgroup's life; only where the launch runs MORE than one round of workgroups (else the wait is pure loss:
+        // measured +5..9 % on the 384-workgroup launches).  FACL_RS_PHASE=<ticks per k-step> overrides, 0 = off.
+        static const int per_ks = getenv("FACL_RS_PHASE") ? atoi(getenv("FACL_RS_PHASE")) : 30;
+        const long long wgs = (long long)(g.N / 256) * ((g.M + 32 * rs_waves(g.h3) - 1) / (32 * rs_waves(g.h3)));
+        g.first_round = 512;
+        g.phase_ticks = (per_ks > 0 && wgs > g.first_round && rs_waves(g.h3) == RS_WAVES) ? per_ks * (g.K >> 4) + 500 : 0;
+    }
     // the dynamic-LDS attribute is per device: one flag per device ordinal (a process may drive several devices, and a
     // forward on the main thread can race a backward on the autograd thread: the worst case sets the attribute twice)
     static bool attr_done_dev[64] = {};

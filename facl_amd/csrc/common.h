@@ -26,6 +26,20 @@ static inline int facl_set_dynamic_lds(bool (&done)[64], const void* const* fns,
     return 0;
 }
 
+// Phase offset between the workgroups that share a CU.  Co-resident workgroups of one launch start together and do identical work,
+// so they stay in lockstep: every wave of a SIMD waits for memory at the same time and competes for the pipes at the same time.
+// The workgroup in the CU's second thread-group slot (HW_ID.TG_ID bit 0) waits `ticks` of the 100-MHz real-time counter ONCE, at
+// its start; in a persistent (grid-stride) kernel that offset then persists.  ticks <= 0: no-op.
+__device__ __forceinline__ void facl_phase_wait(int ticks) {
+    if (ticks <= 0) return;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if ((hw >> 16) & 1u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // "sign of gamma" arguments (facl_sa_fwd3, facl_gemm_fwd_segmax): callers may pass the BatchNorm weight itself -- the
 // kernels only use its sign, with sign(0) = +1 (a +-1 array, the round-1 convention, maps onto itself)
 __device__ __forceinline__ float sgn_of(float g) { return g < 0.f ? -1.f : 1.f; }

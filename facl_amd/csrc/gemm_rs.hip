@@ -217,17 +217,12 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void k_gemm_rs(RsArgs g) 
     constexpr int NPL = H3 ? 2 : 3;                                     // planes per fragment (fp16x3 / bf16x6, common.h)
     constexpr int WPP = RS_CT * NPL / WV;                         // 1-KiB weight pieces a wave issues per k-step
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (g.phase_ticks > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < g.first_round) {
-        // Phase-offset experiment: the two workgroups of a CU start together and take the same time, so they stay in phase for
-        // the whole launch -- both in the main loop (MFMA pipe shared) or both draining their output (pipe idle).  The one in
-        // the CU's second thread-group slot (HW_ID.TG_ID) waits here once; the offset then persists round after round.
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if ((hw >> 16) & 1u) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.phase_ticks) __builtin_amdgcn_s_sleep(32);
-        }
-    }
+    // The two workgroups of a CU start together and take the same time, so they stay in phase for the whole launch -- both in
+    // the main loop (MFMA pipe shared) or both draining their output (pipe idle).  On multi-round launches the first-round
+    // workgroup in the CU's second slot waits about half a workgroup's life once (common.h: facl_phase_wait); the offset
+    // then persists round after round.  (The persistent set-abstraction kernels do not need it: k_sa_bwd2_sb with the same
+    // offset measured unchanged, gpurun_out/r5v_ab.log.)
+    if ((int)(blockIdx.x + gridDim.x * blockIdx.y) < g.first_round) facl_phase_wait(g.phase_ticks);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, q = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* const wring = lds;

@@ -1099,7 +1099,8 @@ extern "C" int facl_gemm_rs_wgrad(const float* dy, const float* y, int64_t M, in
     dim3 grid(K / 128, N / 512, nz);
     const dim3 blk(64 * WG_WAVES);
     // dynamic LDS: plane ring (48 / 32 KiB) + per-wave staging (WIDE: the dy image, 8.5 KiB per wave; else the 4-KiB epilogue tile)
-    static const int wide = getenv("FACL_WGRAD_WIDE") ? atoi(getenv("FACL_WGRAD_WIDE")) : 1;      // 0: dword fragment loads (A/B)
+    static const int wide_env = getenv("FACL_WGRAD_WIDE") ? atoi(getenv("FACL_WGRAD_WIDE")) : 1;  // 0: dword fragment loads (A/B)
+    const int wide = wide_env && !(((uintptr_t)dy) & 15);                                          // the 16-byte row loads need an aligned dy
     const int lds3 = 2 * (2 * 4 * 3 * 64) * 16, lds2 = 2 * (2 * 4 * 2 * 64) * 16;
     const int stg_n = WG_WAVES * 32 * 32 * 4, stg_w = WG_WAVES * 32 * WG_TP * 4;
     static bool attr_done[64] = {};

@@ -900,7 +900,7 @@ extern "C" int facl_sa_bwd2(const float* dz2f, const float* y2f, const float* x,
         const int grid = (int)(nunits < SA_GRID * 8 ? (nunits + 3) / 4 : 2 * SA_GRID);       // 2 workgroups of 4 waves per CU
         int rc = facl_sa_bwd2_sb_launch(dz2f, y2f, x, (int)nunits, D, bw2, W2, l1tab, (double*)ws, grid, a1amax, st);
         if (rc) return rc;
-        return facl_reduce_rows((const double*)ws, grid * 4, B2_V, out, st);
+        return facl_reduce_rows((const double*)ws, grid, B2_V, out, st);       // one row per workgroup (combined in LDS)
     }
     const int grid = (int)(nunits < SA_GRID * 4 ? (nunits + 3) / 4 : SA_GRID);
     const size_t lds = (1024 + 128 + 64) * sizeof(float4) + 4 * (2 * 64 * TQ + 64 * 8) * sizeof(float);

@@ -352,35 +352,49 @@ __global__ __launch_bounds__(64 * B2S_WAVES, 2) void k_sa_bwd2_sb(
             WAVE_LDS_FENCE();                               // the next half unit overwrites the image (and xs4 after ct = 1)
         }
     }
-    double* row = part + (size_t)wave_g * B2_V;
+    // ONE partial row per WORKGROUP: the four waves add their tiles in wave order into an fp64 area over the (dead) images and the
+    // workgroup writes it out coalesced -- a quarter of the 75 MB of per-wave rows the reduction used to read back (its first
+    // level: 13.6 -> ~4 us)
+    __syncthreads();
+    double* comb = reinterpret_cast<double*>(tab + 64 + B2S_WAVES * 64);
+    float r1v[2][5];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int ct1 = 0; ct1 < 2; ++ct1)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int d = 0; d < 5; ++d) r1v[ct1][d] = r1[ct1][d] + __shfl_xor(r1[ct1][d], 32, 64);   // the two lane halves hold different positions of the same c1
+    for (int w = 0; w < B2S_WAVES; ++w) {
+        if (wave == w) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) row[(32 * a + rowmap(r, h)) * 64 + 32 * b + q] = (double)dw2[a][b][r];
-    // R1 rows: x_0..x_{D-1}, 1, zeros; the two lane halves hold different positions of the same c1
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int ct1 = 0; ct1 < 2; ++ct1) {
-        float v[5];
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int d = 0; d < 5; ++d) v[d] = r1[ct1][d] + __shfl_xor(r1[ct1][d], 32, 64);
-        if (h == 0) {
-            double* rr = row + 64 * 64 + 32 * ct1 + q;
+                    for (int r = 0; r < 16; ++r) {
+                        double* d = comb + (32 * a + rowmap(r, h)) * 64 + 32 * b + q;
+                        *d = (w == 0 ? 0.0 : *d) + (double)dw2[a][b][r];
+                    }
+            if (h == 0) {                                      // R1 rows: x_0..x_{D-1}, 1, zeros
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                float o = 0.f;
-                if (d < D) o = v[d];
-                else if (d == D) o = v[4];
-                rr[d * 64] = (double)o;
+                for (int ct1 = 0; ct1 < 2; ++ct1)
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        float o = 0.f;
+                        if (d < D) o = r1v[ct1][d];
+                        else if (d == D) o = r1v[ct1][4];
+                        double* dd = comb + 64 * 64 + d * 64 + 32 * ct1 + q;
+                        *dd = (w == 0 ? 0.0 : *dd) + (double)o;
+                    }
             }
         }
+        __syncthreads();
     }
+    double* row = part + (size_t)blockIdx.x * B2_V;
+    for (int i = threadIdx.x; i < B2_V; i += 64 * B2S_WAVES) row[i] = comb[i];
 }
 
 }  // namespace
 
-// launcher for facl_sa_bwd2 (sa_bwd.hip): `grid` workgroups of B2S_WAVES waves, one partial row per wave in `ws`
+// launcher for facl_sa_bwd2 (sa_bwd.hip): `grid` workgroups of B2S_WAVES waves, one partial row per WORKGROUP in `ws`
 int facl_sa_bwd2_sb_launch(const float* dz2f, const float* y2f, const float* x, int nunits, int D, const float* bw2,
                            const float* W2, const float* l1tab, double* ws, int grid, const uint32_t* a1amax, hipStream_t st) {
     const size_t lds = (1536 + 64 + B2S_WAVES * 64) * sizeof(float4) + B2S_WAVES * (size_t)B2S_IMG;

@@ -12,6 +12,33 @@ namespace {
 // part[rows][V] -> out[V]  (deterministic: fixed order, no atomics).  Block = 64 columns x 16 row groups; blockIdx.y
 // selects a contiguous slice of `rows_per_block` rows and writes row blockIdx.y of `out` (two-level reduction: the
 // partial-sum matrices are up to 12 MB and V/64 blocks alone left the kernel latency-bound at ~10 us a call).
+template <typename T>
+__global__ __launch_bounds__(1024) void k_reduce_rows_t1(const T* __restrict__ part, int rows, int V,
+                                                         int rows_per_block, double* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int v = blockIdx.x * 64 + col;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    double s0 = 0, s1 = 0;
+    if (v < V) {
+        int r = r0 + rg;
+        for (; r + 16 < r1; r += 32) {
+            s0 += (double)part[(size_t)r * V + v];
+            s1 += (double)part[(size_t)(r + 16) * V + v];
+        }
+        if (r < r1) s0 += (double)part[(size_t)r * V + v];
+    }
+    red[rg][col] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && v < V) {
+        double t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][col];
+        out[(size_t)blockIdx.y * V + v] = t;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ part, int rows, int V,
                                                       int rows_per_block, double* __restrict__ out) {
     __shared__ double red[16][64];
@@ -268,6 +295,14 @@ int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream
     } else {
         hipLaunchKernelGGL(k_reduce_rows, dim3(cb, 1), dim3(1024), 0, st, part, rows, V, rows, out);
     }
+    return facl_launch_status();
+}
+
+// fp32 partial rows (a kernel whose per-workgroup sums are fp32 anyway writes and re-reads half the bytes): part[rows][V]
+// floats -> out[V] doubles, rows added in the same fixed order as facl_reduce_rows' single level
+int facl_reduce_rows_f32(const float* part, int rows, int V, double* out, hipStream_t st) {
+    const int cb = (V + 63) / 64;
+    hipLaunchKernelGGL((k_reduce_rows_t1<float>), dim3(cb, 1), dim3(1024), 0, st, part, rows, V, rows, out);
     return facl_launch_status();
 }
 

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
+int facl_reduce_rows_f32(const float* part, int rows, int V, double* out, hipStream_t st);
 
 namespace {
 
@@ -642,13 +643,14 @@ void k_sa_bwd_w3p(const float* __restrict__ y2f, int nunits, const float* __rest
         }
         __syncthreads();
     }
-    double* row = part + (size_t)blockIdx.x * W3_V;
-    for (int i = threadIdx.x; i < 256 * 64; i += 512) row[i] = (double)comb[(i >> 6) * 65 + (i & 63)];
+    // the workgroup's row as fp32 (its sums ARE fp32): half the bytes of the 42 MB of fp64 rows, out and back in (facl_reduce_rows_f32)
+    float* row = reinterpret_cast<float*>(part) + (size_t)blockIdx.x * W3_V;
+    for (int i = threadIdx.x; i < 256 * 64; i += 512) row[i] = comb[(i >> 6) * 65 + (i & 63)];
     for (int i = threadIdx.x; i < 64 * 64; i += 512) {
         const int a = i >> 6, b = i & 63;
-        row[256 * 64 + i] = (double)((a >= 32 && b < 32) ? gcomb[b * 64 + a] : gcomb[i]);     // lower-left = upper-right^T
+        row[256 * 64 + i] = (a >= 32 && b < 32) ? gcomb[b * 64 + a] : gcomb[i];               // lower-left = upper-right^T
     }
-    if (threadIdx.x < 64) row[256 * 64 + 64 * 64 + threadIdx.x] = (double)scomb[threadIdx.x];
+    if (threadIdx.x < 64) row[256 * 64 + 64 * 64 + threadIdx.x] = scomb[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -873,6 +875,9 @@ extern "C" int facl_sa_bwd_w3(const float* y2f, int64_t nunits, const float* bnc
         const void* fns[1] = {(const void*)k_sa_bwd_w3p};
         if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, (int)lds)) return rc;
         hipLaunchKernelGGL(k_sa_bwd_w3p, dim3(grid), dim3(512), lds, st, y2f, (int)nunits, bnc2, coef, arg, (double*)ws, a2amax);
+        int rc = facl_launch_status();
+        if (rc) return rc;
+        return facl_reduce_rows_f32((const float*)ws, grid, W3_V, out, st);
     } else {
         const size_t lds = 32 * sizeof(float4) + (256 * 65 + 64 * 64 + 64 + 4 * 64 * TP) * sizeof(float);
         static bool attr_done[64] = {};

@@ -908,6 +908,54 @@ __global__ void k_sum_slices(const float* __restrict__ part, int nz, long long n
     }
 }
 
+
+// The same with the slices spread over four thread groups of the workgroup (round 4): thread (column, phase) adds a contiguous
+// quarter of the slices in order, the four partial sums meet in LDS and are added in phase order -- still one fixed order, so
+// deterministic, with four times the loads in flight per output (the serial form ran at 2.6-4 TB/s on 33-67 MB of slices).
+// FACL_SUM_SLICES_PAR=0 restores the serial kernel (A/B).
+__global__ __launch_bounds__(256) void k_sum_slices_par(const float* __restrict__ part, int nz, long long n4, float* __restrict__ out) {
+    __shared__ float4 red[3][64];
+    const int col = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + col;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    const int per = (nz + 3) >> 2;
+    const int z0 = ph * per, z1 = z0 + per < nz ? z0 + per : nz;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        int z = z0;
+        for (; z + 3 < z1; z += 4) {
+            const float4 v0 = p4[(size_t)z * n4 + i], v1 = p4[(size_t)(z + 1) * n4 + i];
+            const float4 v2 = p4[(size_t)(z + 2) * n4 + i], v3 = p4[(size_t)(z + 3) * n4 + i];
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; z < z1; ++z) {
+            const float4 v = p4[(size_t)z * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if (ph) red[ph - 1][col] = s;
+    __syncthreads();
+    if (ph == 0 && i < n4) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { const float4 v = red[t][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+static int launch_k_sum_slices(const float* slices, int nz, long long n4, float* dW, hipStream_t st) {
+    static const int par = getenv("FACL_SUM_SLICES_PAR") ? atoi(getenv("FACL_SUM_SLICES_PAR")) : 1;
+    if (par && nz >= 8) {
+        hipLaunchKernelGGL(k_sum_slices_par, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, slices, nz, n4, dW);
+    } else {
+        const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_sum_slices, dim3(grid), dim3(256), 0, st, slices, nz, n4, dW);
+    }
+    return facl_launch_status();
+}
+
 template <int LA, int LB, bool PRO, int NP>
 int launch_sb_np(const GemmArgs& g, int nz, long long big, hipStream_t st, int* rows_per_part) {
     if (sbk_fits(g, nz)) {
@@ -1047,9 +1095,7 @@ static int gemm_wgrad_p(const float* dy, const float* a, int64_t M, int N, int K
     int rc = launch<IC, IC, false>(g, nz, st, nullptr);
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;
-    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_sum_slices, dim3(grid), dim3(256), 0, st, slices, nz, n4, dW);
-    return facl_launch_status();
+    return launch_k_sum_slices(slices, nz, n4, dW, st);
 }
 
 // dW (N,K) = dy^T (N,M) relu(pscale * y + pshift) (M,K): the weight gradient of a layer whose input activation is the
@@ -1075,9 +1121,7 @@ static int gemm_wgrad_pro_p(const float* dy, const float* y, int64_t M, int N, i
     int rc = facl_launch_status();
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;
-    const int rgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_sum_slices, dim3(rgrid), dim3(256), 0, st, slices, nz, n4, dW);
-    return facl_launch_status();
+    return launch_k_sum_slices(slices, nz, n4, dW, st);
 }
 
 // fp16x3 weight gradient on the 128x128-tile kernel: dW (N,K) = dy^T f(y), f = relu(pscale*y + pshift) per column when pscale
@@ -1104,9 +1148,7 @@ extern "C" int facl_gemm_wgrad_h3(const float* dy, const float* y, int64_t M, in
     int rc = facl_launch_status();
     if (rc) return rc;
     const long long n4 = (long long)N * K / 4;
-    const int rgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_sum_slices, dim3(rgrid), dim3(256), 0, st, slices, nz, n4, dW);
-    return facl_launch_status();
+    return launch_k_sum_slices(slices, nz, n4, dW, st);
 }
 
 extern "C" int facl_gemm_wgrad_pro(const float* dy, const float* y, int64_t M, int N, int K, int ldy, const float* pscale,

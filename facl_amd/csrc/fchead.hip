@@ -274,25 +274,52 @@ __global__ __launch_bounds__(1024) void k_col_sums(const float* __restrict__ x, 
 
 // gobaol_max_pool into the stacked input of netR_FC: h (G*B + B, C) = [x ; max over the G views of x], arg (B, C) = the
 // first view that attains the maximum (rows.hip: k_viewmax_fwd, plus the copy of the rows it reads anyway)
+// Workgroup = 64 (clip, channel quad) items x 4 view phases: phase p walks a contiguous quarter of the views, the four candidates
+// meet in LDS and are merged in view order with the same rule (strictly greater, or NaN, replaces), so the first maximum / the last
+// NaN wins exactly as in the one-thread walk over 24 views this replaces (an 11 us chain of loads on 32 workgroups).
 __global__ __launch_bounds__(256) void k_viewmax_stack(const float* __restrict__ x, int G, int B, int C4, float* __restrict__ h,
                                                        int* __restrict__ arg) {
-    const int i = blockIdx.x * 256 + threadIdx.x;          // (b, c4)
-    if (i >= B * C4) return;
-    const int b = i / C4, c4 = i - b * C4;
-    float4 best = reinterpret_cast<const float4*>(x)[(size_t)b * C4 + c4];
-    reinterpret_cast<float4*>(h)[(size_t)b * C4 + c4] = best;
-    int4 bi = make_int4(0, 0, 0, 0);
-    for (int g = 1; g < G; ++g) {
-        const size_t o = ((size_t)g * B + b) * C4 + c4;
-        const float4 v = reinterpret_cast<const float4*>(x)[o];
-        reinterpret_cast<float4*>(h)[o] = v;
-        if (v.x > best.x || v.x != v.x) { best.x = v.x; bi.x = g; }
-        if (v.y > best.y || v.y != v.y) { best.y = v.y; bi.y = g; }
-        if (v.z > best.z || v.z != v.z) { best.z = v.z; bi.z = g; }
-        if (v.w > best.w || v.w != v.w) { best.w = v.w; bi.w = g; }
+    __shared__ float4 sb[3][64];
+    __shared__ int4 si[3][64];
+    const int it = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + it;                    // (b, c4)
+    const bool live = i < B * C4;
+    const int b = live ? i / C4 : 0, c4 = live ? i - b * C4 : 0;
+    const int per = (G + 3) >> 2;
+    const int g0 = ph * per, g1 = g0 + per < G ? g0 + per : G;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 bi = make_int4(-1, -1, -1, -1);                   // -1: this phase saw no view
+    if (live && g0 < g1) {
+        const size_t o0 = ((size_t)g0 * B + b) * C4 + c4;
+        best = reinterpret_cast<const float4*>(x)[o0];
+        reinterpret_cast<float4*>(h)[o0] = best;
+        bi = make_int4(g0, g0, g0, g0);
+        for (int g = g0 + 1; g < g1; ++g) {
+            const size_t o = ((size_t)g * B + b) * C4 + c4;
+            const float4 v = reinterpret_cast<const float4*>(x)[o];
+            reinterpret_cast<float4*>(h)[o] = v;
+            if (v.x > best.x || v.x != v.x) { best.x = v.x; bi.x = g; }
+            if (v.y > best.y || v.y != v.y) { best.y = v.y; bi.y = g; }
+            if (v.z > best.z || v.z != v.z) { best.z = v.z; bi.z = g; }
+            if (v.w > best.w || v.w != v.w) { best.w = v.w; bi.w = g; }
+        }
     }
-    reinterpret_cast<float4*>(h)[((size_t)G * B + b) * C4 + c4] = best;
-    reinterpret_cast<int4*>(arg)[i] = bi;
+    if (ph) { sb[ph - 1][it] = best; si[ph - 1][it] = bi; }
+    __syncthreads();
+    if (ph == 0 && live) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float4 v = sb[t][it];
+            const int4 vi = si[t][it];
+            if (vi.x < 0) continue;                        // empty phase (fewer than four views per phase quarter)
+            if (v.x > best.x || v.x != v.x) { best.x = v.x; bi.x = vi.x; }
+            if (v.y > best.y || v.y != v.y) { best.y = v.y; bi.y = vi.y; }
+            if (v.z > best.z || v.z != v.z) { best.z = v.z; bi.z = vi.z; }
+            if (v.w > best.w || v.w != v.w) { best.w = v.w; bi.w = vi.w; }
+        }
+        reinterpret_cast<float4*>(h)[((size_t)G * B + b) * C4 + c4] = best;
+        reinterpret_cast<int4*>(arg)[i] = bi;
+    }
 }
 
 inline bool fc_shape_ok(int64_t M, int64_t R, int C) {
@@ -389,6 +416,6 @@ extern "C" int facl_viewmax_stack(const float* x, int G, int B, int C, float* h,
     if (G < 1 || B < 1 || C < 4 || (C & 3)) return FACL_E_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)h) | ((uintptr_t)arg)) & 15) return FACL_E_ALIGN;
     const int n = B * (C / 4);
-    hipLaunchKernelGGL(k_viewmax_stack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, G, B, C / 4, h, arg);
+    hipLaunchKernelGGL(k_viewmax_stack, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, G, B, C / 4, h, arg);
     return facl_launch_status();
 }

@@ -369,11 +369,14 @@ extern "C" int facl_sa_l1tab(const float* W1, const float* b1, int D, const floa
 namespace {
 
 // G3 = W3^T diag(g) W3,  h3' = W3^T (-(1/P) s3 dbeta3 + g (b3 - mean3)),  g = -(1/P) s3 dgamma3 invstd3
+// Workgroup = 64 outputs x 4 channel quarters: thread (output, quarter) adds its 64 channels in order, the quarters meet in LDS and
+// are added in quarter order (one fixed order: deterministic).  65 workgroups instead of 17 whole-W3 ones (the 256-term fp64 dots
+// of one thread per output were a 14 us serial chain between k_sa_bwd0 and k_sa_bwd1).
 __global__ __launch_bounds__(256) void k_sa_bwd_consts3(const double* __restrict__ sums0, const float* __restrict__ bnc3,
                                                         const float* __restrict__ W3, const float* __restrict__ b3,
                                                         double P, float* __restrict__ G3, float* __restrict__ h3) {
     __shared__ double g[256], hc[256];
-    __shared__ float w3s[256 * 64];                      // W3 staged once per block: the 256-term dots read LDS, not L2
+    __shared__ double red[3][64];
     const int c = threadIdx.x;
     {
         const double mean = bnc3[c], inv = bnc3[256 + c], sc = bnc3[512 + c];
@@ -381,20 +384,23 @@ __global__ __launch_bounds__(256) void k_sa_bwd_consts3(const double* __restrict
         g[c] = gg;
         hc[c] = -(sc * sums0[2 * c]) / P + gg * ((double)b3[c] - mean);
     }
-    for (int i = threadIdx.x; i < 4096; i += 256)
-        reinterpret_cast<float4*>(w3s)[i] = reinterpret_cast<const float4*>(W3)[i];
     __syncthreads();
-    const int o = blockIdx.x * 256 + threadIdx.x;       // 0..4095: G3[k][j]; 4096..4159: h3[j]
-    if (o < 4096) {
-        const int k = o >> 6, j = o & 63;
-        double s = 0;
-        for (int cc = 0; cc < 256; ++cc) s += g[cc] * (double)w3s[cc * 64 + k] * (double)w3s[cc * 64 + j];
-        G3[o] = (float)s;
-    } else if (o < 4160) {
-        const int j = o - 4096;
-        double s = 0;
-        for (int cc = 0; cc < 256; ++cc) s += hc[cc] * (double)w3s[cc * 64 + j];
-        h3[j] = (float)s;
+    const int j = threadIdx.x & 63, qt = threadIdx.x >> 6;          // output column, channel quarter
+    const int k = blockIdx.x;                                        // 0..63: row k of G3; 64: h3
+    double s = 0;
+    if (k < 64) {
+#pragma unroll 8
+        for (int cc = 64 * qt; cc < 64 * qt + 64; ++cc) s += g[cc] * (double)W3[cc * 64 + k] * (double)W3[cc * 64 + j];
+    } else {
+#pragma unroll 8
+        for (int cc = 64 * qt; cc < 64 * qt + 64; ++cc) s += hc[cc] * (double)W3[cc * 64 + j];
+    }
+    if (qt) red[qt - 1][j] = s;
+    __syncthreads();
+    if (qt == 0) {
+        s += red[0][j]; s += red[1][j]; s += red[2][j];
+        if (k < 64) G3[k * 64 + j] = (float)s;
+        else h3[j] = (float)s;
     }
 }
 
@@ -470,7 +476,7 @@ extern "C" int facl_sa_bwd_consts3(const double* sums0, const float* bnc3, const
                                    float* G3, float* h3, void* stream) {
     if (!sums0 || !bnc3 || !W3 || !b3 || !G3 || !h3) return FACL_E_NULL;
     if (P < 1) return FACL_E_SHAPE;
-    hipLaunchKernelGGL(k_sa_bwd_consts3, dim3(17), dim3(256), 0, (hipStream_t)stream, sums0, bnc3, W3, b3, P, G3, h3);
+    hipLaunchKernelGGL(k_sa_bwd_consts3, dim3(65), dim3(256), 0, (hipStream_t)stream, sums0, bnc3, W3, b3, P, G3, h3);
     return facl_launch_status();
 }
 

@@ -4,6 +4,7 @@
 // Algorithmic bytes: stats R*C*4 read; apply 2*R*C*4; segmax R*C*4 read; bwd_stats 2*R*C*4 read;
 // bwd_apply 3*R*C*4; bwd_sparse 2*R*C*4.
 #include "common.h"
+#include <stdlib.h>
 
 int facl_reduce_rows(const double* part, int rows, int V, double* out, hipStream_t st);
 
@@ -200,6 +201,27 @@ __global__ __launch_bounds__(256) void k_segmax_bwd_stats(const float* __restric
     part[(size_t)blockIdx.y * 2 * C + 2 * c + 1] = g;
 }
 
+// The same sums from ymax (M, C) = max over the S rows of sign(gamma) * y, which the forward's max-pool epilogue returns anyway: the
+// value at the argmax is sign(gamma) * ymax EXACTLY, so the 4-byte gather y[(m*S + arg)*C + c] -- one 128-byte line per element,
+// 100 MB of fills for 3 MB of values, 15 us -- is not needed.  bnc row 4 = sign(gamma).
+__global__ __launch_bounds__(256) void k_segmax_bwd_stats_ymax(const float* __restrict__ dxpre, const float* __restrict__ xpre,
+                                                               const float* __restrict__ ymax, int Mrows, int C,
+                                                               const float* __restrict__ bnc, double* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mean = bnc[c], inv = bnc[C + c], sg = bnc[4 * C + c];
+    double s = 0, g = 0;
+    for (int m = blockIdx.y; m < Mrows; m += gridDim.y) {
+        const size_t o = (size_t)m * C + c;
+        const float d = xpre[o] > 0.f ? dxpre[o] : 0.f;
+        const float v = sg * ymax[o];
+        s += (double)d;
+        g += (double)d * (double)((v - mean) * inv);
+    }
+    part[(size_t)blockIdx.y * 2 * C + 2 * c] = s;
+    part[(size_t)blockIdx.y * 2 * C + 2 * c + 1] = g;
+}
+
 __global__ __launch_bounds__(256) void k_segmax_bwd_apply(const float* __restrict__ dxpre, const float* __restrict__ xpre,
                                                           const float* __restrict__ y, const int* __restrict__ arg,
                                                           int S, int C, const float* __restrict__ bnc,
@@ -365,6 +387,82 @@ __global__ __launch_bounds__(256) void k_normalize_map(const float* __restrict__
     }
 }
 
+// The same for FOUR rows per workgroup (C <= 1024, K = 4 * KPW): wave w normalises row 4b + w into LDS, then owns the outputs
+// k = w, w + 4, ..: each float4 of a mapping row is loaded once (coalesced, all KPW rows' loads in flight) and multiplied into the
+// four rows' accumulators; the wave's 4 * KPW = 64 partial sums are then reduced TOGETHER by a halving butterfly (63 exchanges,
+// independent within a step; lane L ends up with the total of value L) instead of one 6-step chain per output.  The one-row form
+// walked its mapping rows with 16-byte pieces of 64 different cache lines per load instruction.
+template <int KPW, int NI>
+__global__ __launch_bounds__(256) void k_normalize_map4(const float* __restrict__ x, int M, const float* __restrict__ Wm,
+                                                        float* __restrict__ xn, float* __restrict__ code) {
+    static_assert(KPW * 4 == 64, "the butterfly leaves one total per lane");
+    constexpr int K = 4 * KPW, C4 = 64 * NI, C = 4 * C4;
+    __shared__ __attribute__((aligned(16))) float rows[4][C];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = blockIdx.x * 4;
+    // this wave's slices of the mapping rows do not depend on x: requested first, they fly under the normalisation (inside the
+    // replayed step the matrix is cold -- nothing has touched it since the previous step)
+    const float4* w4 = reinterpret_cast<const float4*>(Wm) + (size_t)wave * C4 + lane;
+    float4 b[NI][KPW];
+#pragma unroll
+    for (int t = 0; t < NI; ++t)
+#pragma unroll
+        for (int kk = 0; kk < KPW; ++kk) b[t][kk] = w4[(size_t)(4 * kk) * C4 + 64 * t];
+    {
+        const int m = m0 + wave;                           // wave-uniform
+        float4 v[NI];
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int i = lane + 64 * t;
+            v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M && i < C4) v[t] = reinterpret_cast<const float4*>(x + (size_t)m * C)[i];
+            ss = fmaf(v[t].x, v[t].x, ss); ss = fmaf(v[t].y, v[t].y, ss); ss = fmaf(v[t].z, v[t].z, ss); ss = fmaf(v[t].w, v[t].w, ss);
+        }
+        ss = wave_sum_f32(ss);
+        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int i = lane + 64 * t;
+            if (i < C4) {
+                const float4 o = make_float4(v[t].x * inv, v[t].y * inv, v[t].z * inv, v[t].w * inv);
+                reinterpret_cast<float4*>(rows[wave])[i] = o;
+                if (m < M) reinterpret_cast<float4*>(xn + (size_t)m * C)[i] = o;
+            }
+        }
+    }
+    __syncthreads();
+    float a[64];                                           // [kk * 4 + row]
+#pragma unroll
+    for (int j = 0; j < 64; ++j) a[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        float4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = reinterpret_cast<const float4*>(rows[q])[lane + 64 * t];
+#pragma unroll
+        for (int kk = 0; kk < KPW; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u = a[4 * kk + q];
+                u = fmaf(r[q].x, b[t][kk].x, u); u = fmaf(r[q].y, b[t][kk].y, u); u = fmaf(r[q].z, b[t][kk].z, u); u = fmaf(r[q].w, b[t][kk].w, u);
+                a[4 * kk + q] = u;
+            }
+    }
+    // halving butterfly: after the step with offset o, value index bit log2(o) equals the lane's bit log2(o)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const bool hi = (lane & o) != 0;
+#pragma unroll
+        for (int j = 0; j < o; ++j) {
+            const float keep = hi ? a[j + o] : a[j], send = hi ? a[j] : a[j + o];
+            a[j] = keep + __shfl_xor(send, o, 64);
+        }
+    }
+    const int kk = lane >> 2, q = lane & 3;
+    if (m0 + q < M) code[(size_t)(m0 + q) * K + wave + 4 * kk] = a[0];
+}
+
 // dx (G*B, C) += dout routed to the winning view's row (the rows of dx already hold the other gradient path of x_pre)
 __global__ __launch_bounds__(256) void k_viewmax_bwd_add(const float* __restrict__ dout, const int* __restrict__ arg,
                                                          int B, int C4, float* __restrict__ dx) {
@@ -480,6 +578,19 @@ extern "C" int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, cons
     return facl_reduce_rows((const double*)ws, gy, 2 * C, sums, st);
 }
 
+extern "C" int facl_segmax_bwd_stats_ymax(const float* dxpre, const float* xpre, const float* ymax, int64_t M, int C,
+                                          const float* bnc, double* sums, void* ws, void* stream) {
+    if (!dxpre || !xpre || !ymax || !bnc || !sums || !ws) return FACL_E_NULL;
+    if (M < 1 || M > 0x7fffffff || C < 1 || 2 * C > 4608) return FACL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int gy = rows_grid_y((int)M, C);
+    hipLaunchKernelGGL(k_segmax_bwd_stats_ymax, dim3((C + 255) / 256, gy), dim3(256), 0, st, dxpre, xpre, ymax, (int)M, C, bnc,
+                       (double*)ws);
+    int rc = facl_launch_status();
+    if (rc) return rc;
+    return facl_reduce_rows((const double*)ws, gy, 2 * C, sums, st);
+}
+
 extern "C" int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                                      int64_t M, int S, int C, const float* bnc, const float* kk, float* dy,
                                      void* stream) {
@@ -544,7 +655,15 @@ extern "C" int facl_normalize_map(const float* x, int64_t M, int C, const float*
     if (M < 0 || M > 0x7fffffff || C < 16 || (C & 15) || C > 4096 || K < 1 || K > 256) return FACL_E_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)Wm) | ((uintptr_t)x_nor)) & 15) return FACL_E_ALIGN;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(k_normalize_map, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, C, Wm, K, x_nor, code);
+    static const int four = getenv("FACL_NORMMAP4") ? atoi(getenv("FACL_NORMMAP4")) : 1;     // A/B knob
+    if (four && C == 512 && K == 64)
+        hipLaunchKernelGGL((k_normalize_map4<16, 2>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (int)M, Wm,
+                           x_nor, code);
+    else if (four && C == 256 && K == 64)
+        hipLaunchKernelGGL((k_normalize_map4<16, 1>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (int)M, Wm,
+                           x_nor, code);
+    else
+        hipLaunchKernelGGL(k_normalize_map, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, C, Wm, K, x_nor, code);
     return facl_launch_status();
 }
 

@@ -757,7 +757,7 @@ class _Net3DV3(torch.autograd.Function):
         _lib.tap_relu("relu_t1", y1, bnc1[2], bnc1[3])
         _lib.tap_relu("relu_t2", y2, bnc2[2], bnc2[3])
         _lib.tap_relu("relu_t3", a=xpre)
-        ctx.save_for_backward(pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg)
+        ctx.save_for_backward(pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg, ymax)
         ctx.count, ctx.reduce_fn, ctx.training, ctx.S = count, reduce_fn, training, S
         return xpre
 
@@ -767,7 +767,7 @@ class _Net3DV3(torch.autograd.Function):
             raise RuntimeError("backward through the eval-mode (folded BN) encoder is not supported")
         bp = backward_precision(ctx.prec)
         lib = _lib.load_library()
-        pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg = ctx.saved_tensors
+        pooled, centers, W1, W2, W3, y1, y2, y3, bnc1, bnc2, bnc3, xpre, arg, ymax = ctx.saved_tensors
         ws = _Workspace.get(y1.device)
         st = _lib.stream()
         P, S = y1.shape[0], ctx.S
@@ -777,8 +777,9 @@ class _Net3DV3(torch.autograd.Function):
         C3 = y3.shape[1]
         dxpre = dxpre.contiguous()
         sums = _lib.empty((C3, 2), **f64)
-        _lib.check(lib.facl_segmax_bwd_stats(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
-                                             _lib.ptr(bnc3), _lib.ptr(sums), _lib.ptr(ws), st), "facl_segmax_bwd_stats")
+        # y3 at the argmax = sign(gamma3) * ymax exactly: the sums come from the (M, C3) maxima the forward kept, not from a gather
+        _lib.check(lib.facl_segmax_bwd_stats_ymax(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(ymax), M, C3, _lib.ptr(bnc3),
+                                                  _lib.ptr(sums), _lib.ptr(ws), st), "facl_segmax_bwd_stats")
         dbe3, dga3, kk = _bn_bwd_consts(sums, C3, ctx.count, ctx.reduce_fn)
         dy = _lib.empty_like(y3)
         # fp16x3 backward: max|dy| of each of the three gradient tensors, maintained by the kernel that writes it

@@ -250,6 +250,10 @@ int facl_rows_bwd_apply(const float* dout, const float* y, int64_t R, int C, con
                         const float* kk, float* dy, void* stream);
 int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                           int64_t M, int S, int C, const float* bnc, double* sums, void* ws, void* stream);
+/* the same sums from ymax (M,C) = max over the S rows of sign(gamma)*y, as facl_gemm_rs_fwd / facl_gemm_fwd_segmax return it: the
+ * value at the argmax is sign(gamma)*ymax exactly (bnc row 4 holds the sign), so y is not gathered (one cache line per element) */
+int facl_segmax_bwd_stats_ymax(const float* dxpre, const float* xpre, const float* ymax, int64_t M, int C,
+                               const float* bnc, double* sums, void* ws, void* stream);
 int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                           int64_t M, int S, int C, const float* bnc, const float* kk, float* dy, void* stream);
 /* the two dy producers of the BatchNorm backward, also maintaining max|dy| in `amax`: a buffer of FACL_AMAX_WORDS uint32 the

@@ -494,6 +494,35 @@ def test_segmax_bwd_apply_amax_publishes_the_exact_maximum():
     assert float(amax.view(torch.float32).max()) == float(dy.abs().max())
 
 
+def test_segmax_bwd_stats_from_kept_maxima_equals_the_gather():
+    """facl_segmax_bwd_stats_ymax: y at the argmax is sign(gamma) * ymax exactly, so the BatchNorm-backward sums taken from the
+    (M, C) maxima the forward kept are bit-equal to the ones gathered from y through arg (negative gammas and ties included)."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    p = _lib.ptr
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for Mc, S, C in ((96, 64, 1024), (7, 64, 256)):
+        y = torch.randn(Mc * S, C, device=DEV, generator=g)
+        y[: 3 * S] = y[: 3 * S].round()                                    # exact ties inside the first blocks
+        bnc = _bn_consts(C, g)
+        sgn = torch.where(torch.rand(C, device=DEV, generator=g) < 0.4, -1.0, 1.0)
+        bnc[4] = sgn
+        bnc[2] = bnc[2].abs() * sgn                                        # scale carries gamma's sign
+        sy = (y * sgn).view(Mc, S, C)
+        ymax, arg = sy.max(dim=1)
+        arg = (sy == ymax[:, None, :]).int().argmax(dim=1).to(torch.int32)          # first maximum
+        xpre = torch.relu(bnc[2].abs() * ymax + bnc[3]).contiguous()
+        dxpre = torch.randn(Mc, C, device=DEV, generator=g)
+        s1 = _lib.empty(C, 2, dtype=torch.float64, device=DEV)
+        s2 = _lib.empty(C, 2, dtype=torch.float64, device=DEV)
+        _lib.check(lib.facl_segmax_bwd_stats(p(dxpre), p(xpre), p(y), p(arg.contiguous()), Mc, S, C, p(bnc), p(s1), p(_ws()),
+                                             _lib.stream()), "segmax_bwd_stats")
+        _lib.check(lib.facl_segmax_bwd_stats_ymax(p(dxpre), p(xpre), p(ymax.contiguous()), Mc, C, p(bnc), p(s2), p(_ws()),
+                                                  _lib.stream()), "segmax_bwd_stats_ymax")
+        assert torch.equal(s1, s2)
+        assert float(s1.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("sw,sa", [(2.0 ** -12, 1.0), (2.0 ** 6, 1.0), (1.0, 2.0 ** -9), (1.0, 2.0 ** 7), (2.0 ** 20, 2.0 ** -20),
                                    (2.0 ** -25, 2.0 ** 30)])
 @pytest.mark.parametrize("pro", [False, True])

@@ -49,13 +49,15 @@ __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, 
             for (int j = 0; j < D; ++j) acc[D + i * D + j] += (double)v[i] * (double)v[j];
         }
     };
-    // four points' loads in flight per thread (one dependent round trip per point made this a 14 us kernel on 38 MB); the points
+    // eight points' loads in flight per thread (one dependent round trip per point made this a 14 us kernel on 38 MB); the points
     // are added in the same order as before, so the sums are bit-identical
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; p + 3 * stride < P; p += 4 * stride) {
-        float v0[D], v1[D], v2[D], v3[D];
-        load(p, v0); load(p + stride, v1); load(p + 2 * stride, v2); load(p + 3 * stride, v3);
-        add(v0); add(v1); add(v2); add(v3);
+    for (; p + 7 * stride < P; p += 8 * stride) {
+        float v[8][D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) load(p + u * stride, v[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) add(v[u]);
     }
     for (; p < P; p += stride) {
         float v[D];

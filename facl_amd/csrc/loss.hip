@@ -202,19 +202,38 @@ __global__ __launch_bounds__(1024) void k_contrast_pair_reg(const float* __restr
     if ((int)threadIdx.x < nA) rb_s[threadIdx.x] = sp.row_block(threadIdx.x);
     __syncthreads();
     const int total = nA * J;
+    // Element e = tid + 1024 k of the (nA x J) block: row i = e / J, column j = e % J, and j % Bk for the same-clip mask.  The
+    // divisions are taken ONCE per thread and advanced by increments (one wrap at most per step: 1024 % J < J): with a division
+    // pair per element and pass -- 4 x 18 runtime divisions of ~35 instructions each -- this kernel was VALU-bound on its index
+    // arithmetic (23.5 us on 64 workgroups); the offsets are kept for the write pass (bit 31 = masked column).
+    const int di = 1024 / J, dj = 1024 - di * J, djm = dj % Bk, Jm = J % Bk;
+    int wi = (int)threadIdx.x / J, wj = (int)threadIdx.x - wi * J, wjm = wj % Bk;
     float v[CK];
+    unsigned off[CK];
     float mx = 0.f;                                        // masked entries are 0, there is at least one
 #pragma unroll
     for (int k = 0; k < CK; ++k) {
         const int e = threadIdx.x + k * 1024;
         float x = 0.f;                                     // beyond the end: behaves like a masked column
+        off[k] = 0x80000000u;
         if (e < total) {
-            const int i = e / J, j = e - i * J;
-            x = (j % Bk == myclip) ? 0.f : sim[(size_t)(rb_s[i] * B + n) * J + j];
+            const unsigned o = (unsigned)((rb_s[wi] * B + n) * J + wj);
+            const bool masked = wjm == myclip;
+            off[k] = masked ? (o | 0x80000000u) : o;
+            if (!masked) x = sim[o];
         }
         v[k] = x;
         mx = fmaxf(mx, x);
+        wi += di; wj += dj; wjm += djm;
+        if (wj >= J) { wj -= J; ++wi; wjm += Bk - Jm; }
+        if (wjm >= Bk) wjm -= Bk;
+        if (wjm >= Bk) wjm -= Bk;
     }
+    // the positives' similarities do not depend on the log-sum-exp: requested with the block, not behind two reductions
+    float pos = 0.f;
+    size_t ppos = 0;
+    const bool has_pos = (int)threadIdx.x < nS;            // nS <= 1024: at most one per thread
+    if (has_pos) { ppos = sp.pos_index(threadIdx.x); pos = sim[ppos]; }
     mx = block_reduce_max(mx, smf);
     double se = 0;
 #pragma unroll
@@ -224,11 +243,8 @@ __global__ __launch_bounds__(1024) void k_contrast_pair_reg(const float* __restr
     const float lse = mx + (float)log(se);
     double loss_t = 0, dlse_t = 0;
     float dpos = 0.f;
-    size_t ppos = 0;
     const float invB = 1.f / (float)B;
-    for (int s = threadIdx.x; s < nS; s += 1024) {       // nS <= 1024: at most one trip per thread
-        ppos = sp.pos_index(s);
-        const float pos = sim[ppos];
+    if (has_pos) {
         const float m2 = fmaxf(pos, lse);
         const float t = m2 + log1pf(__expf(-fabsf(pos - lse)));
         loss_t += (double)(t - pos);
@@ -240,10 +256,7 @@ __global__ __launch_bounds__(1024) void k_contrast_pair_reg(const float* __restr
 #pragma unroll
     for (int k = 0; k < CK; ++k) {
         const int e = threadIdx.x + k * 1024;
-        if (e < total) {
-            const int i = e / J, j = e - i * J;
-            dsim[(size_t)(rb_s[i] * B + n) * J + j] = (j % Bk == myclip) ? 0.f : dlse * __expf(v[k] - lse);
-        }
+        if (e < total) dsim[off[k] & 0x7fffffffu] = (off[k] >> 31) ? 0.f : dlse * __expf(v[k] - lse);
     }
     if (sp.circle) {                                       // the view that is no anchor: zero gradient row
         float* z = dsim + (size_t)(sp.ord(G - 1) * B + n) * J;
@@ -353,7 +366,7 @@ extern "C" int facl_contrast_pair(const float* sim, int G, int B, int Bk, int J,
     if (G < 2 || B < 1 || Bk < 1 || J != G * Bk) return FACL_E_SHAPE;
     if (clip_offset < 0 || clip_offset + B > Bk) return FACL_E_SHAPE;        // the local clips must be columns of the keys
     hipStream_t st = (hipStream_t)stream;
-    if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024)
+    if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024 && (long long)(G + 1) * B * J < 0x7fffffffLL)
         hipLaunchKernelGGL(k_contrast_pair_reg, dim3(2 * B), dim3(1024), 0, st, sim, G, B, Bk, J, (const long long*)order,
                            clip_offset, dsim, (double*)ws);
     else
@@ -388,7 +401,7 @@ extern "C" int facl_contrast_pair_sum(const float* sim, int G, int B, int Bk, in
     if (G < 2 || B < 1 || Bk < 1 || J != G * Bk) return FACL_E_SHAPE;
     if (clip_offset < 0 || clip_offset + B > Bk) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024)
+    if ((long long)(G - 1) * J <= (long long)CK * 1024 && G <= 1024 && (long long)(G + 1) * B * J < 0x7fffffffLL)
         hipLaunchKernelGGL(k_contrast_pair_reg, dim3(2 * B), dim3(1024), 0, st, sim, G, B, Bk, J, (const long long*)order,
                            clip_offset, dsim, (double*)ws);
     else

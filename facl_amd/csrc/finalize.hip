@@ -131,8 +131,10 @@ __global__ __launch_bounds__(256) void k_rows_act_amax(const float* __restrict__
                                                        unsigned* __restrict__ amax) {
     float m = 0.f;
     const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const int c4 = (int)(i % C4);
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    int c4 = (int)(i0 % C4);
+    const int dc = (int)(stride % C4);
+    for (long long i = i0; i < n4; i += stride, c4 = c4 + dc >= C4 ? c4 + dc - C4 : c4 + dc) {
         const float4 v = reinterpret_cast<const float4*>(y)[i];
         const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
         m = fmaxf(fmaxf(m, fmaxf(fmaf(sc.x, v.x, sh.x), fmaf(sc.y, v.y, sh.y))), fmaxf(fmaf(sc.z, v.z, sh.z), fmaf(sc.w, v.w, sh.w)));

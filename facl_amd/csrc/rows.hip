@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256) void k_rows_stats(const float* __restrict__ y,
 __global__ void k_rows_bn_relu(const float* __restrict__ y, long long n4, int C4, const float* __restrict__ scale,
                                const float* __restrict__ shift, float* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int c4 = (int)(i % C4);
+    // the channel quad advances by stride % C4 per trip (one 64-bit remainder per thread, not one per element: k_sa_pool)
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c4 = (int)(i0 % C4);
+    const int dc = (int)(stride % C4);
+    for (long long i = i0; i < n4; i += stride, c4 = c4 + dc >= C4 ? c4 + dc - C4 : c4 + dc) {
         const float4 v = reinterpret_cast<const float4*>(y)[i];
         const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
         float4 o;
@@ -143,8 +146,10 @@ __global__ void k_rows_bwd_apply(const float* __restrict__ dout, const float* __
                                  const float* __restrict__ bnc, const float* __restrict__ kk,
                                  float* __restrict__ dy) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int c = (int)(i % C);
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = (int)(i0 % C);
+    const int dc = (int)(stride % C);
+    for (long long i = i0; i < n; i += stride, c = c + dc >= C ? c + dc - C : c + dc) {
         const float mean = bnc[c], inv = bnc[C + c], scale = bnc[2 * C + c], shift = bnc[3 * C + c];
         const float v = y[i];
         const float d = fmaf(scale, v, shift) > 0.f ? dout[i] : 0.f;

@@ -803,8 +803,12 @@ __global__ void k_sa_pool(const float* __restrict__ ymax, long long n4, int C4, 
                           const float* __restrict__ shift, float* __restrict__ pooled, unsigned* __restrict__ amax) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     float mx = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int c4 = (int)(i % C4);
+    // the channel quad of element i advances by stride % C4 per trip: two 32-bit remainders per thread instead of a 64-bit one
+    // (~150 instructions) per element -- the kernel was VALU-bound on `i % C4`, not on its 100 MB
+    const unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x;              // < 2^31: the grid is capped well below
+    int c4 = (int)(i0 % (unsigned)C4);
+    const int dc = (int)((unsigned)stride % (unsigned)C4);
+    for (long long i = i0; i < n4; i += stride, c4 = c4 + dc >= C4 ? c4 + dc - C4 : c4 + dc) {
         const float4 y = reinterpret_cast<const float4*>(ymax)[i];
         const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
         const float4 sh = reinterpret_cast<const float4*>(shift)[c4];

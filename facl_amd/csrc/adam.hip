@@ -7,6 +7,7 @@
 //   facl_adam_apply: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v) * inv_sqrt_bc2 + eps)
 #include "common.h"
 #include <math.h>
+#include <stdint.h>
 
 #define FACL_ADAM_MAX_TENSORS 64
 #define FACL_ADAM_CHUNK 2048
@@ -49,6 +50,37 @@ __global__ __launch_bounds__(256) void k_adam_apply(FaclAdamTable tb, const floa
     float* __restrict__ m = tb.m[t];
     float* __restrict__ v = tb.v[t];
     const float step_size = consts[0], isb2 = consts[1];
+    // 16 bytes per lane where the tensor allows it (every tensor of the model does): a quarter of the memory instructions of the
+    // scalar walk below, all of a thread's loads in flight before its first store
+    if (!(n & 3) && !((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15)) {
+        float4 g4[2], m4[2], v4[2], p4[2];
+        int i4[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            i4[k] = (base >> 2) + k * 256 + threadIdx.x;
+            if (4 * i4[k] < n) {
+                g4[k] = reinterpret_cast<const float4*>(g)[i4[k]]; m4[k] = reinterpret_cast<const float4*>(m)[i4[k]];
+                v4[k] = reinterpret_cast<const float4*>(v)[i4[k]]; p4[k] = reinterpret_cast<const float4*>(p)[i4[k]];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (4 * i4[k] >= n) continue;
+            float gg[4] = {g4[k].x, g4[k].y, g4[k].z, g4[k].w}, mm[4] = {m4[k].x, m4[k].y, m4[k].z, m4[k].w};
+            float vv[4] = {v4[k].x, v4[k].y, v4[k].z, v4[k].w}, pp[4] = {p4[k].x, p4[k].y, p4[k].z, p4[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mi = b1 * mm[e] + (1.f - b1) * gg[e];
+                const float vi = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+                mm[e] = mi; vv[e] = vi;
+                pp[e] -= step_size * (mi / (sqrtf(vi) * isb2 + eps));
+            }
+            reinterpret_cast<float4*>(m)[i4[k]] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            reinterpret_cast<float4*>(v)[i4[k]] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            reinterpret_cast<float4*>(p)[i4[k]] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < FACL_ADAM_CHUNK / 256; ++k) {
         const int i = base + k * 256 + threadIdx.x;

@@ -411,6 +411,7 @@ def main():
             port = sk.getsockname()[1]
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        fdist.full_graph_env()
         tdist.init_process_group("nccl", rank=0, world_size=1)
         fdist.is_distributed = lambda: True                 # is_distributed() is world_size > 1: force the hooks on
         import facl_amd.train_common as _tc

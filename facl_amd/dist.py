@@ -33,9 +33,20 @@ def init_from_env(backend=None):
     # (non-zero exit), the launcher then stops the other ranks.  FACL_DIST_TIMEOUT_S overrides (first-iteration RCCL
     # set-up of 8 ranks takes seconds, a 3 ms step never legitimately waits two minutes).
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    full_graph_env()
     timeout = datetime.timedelta(seconds=float(os.environ.get("FACL_DIST_TIMEOUT_S", "120")))
     dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world
+
+
+def full_graph_env():
+    """OPT-IN FACL_DP_GRAPH=full only (call before the process group exists).  Observed once in ~10 one-rank rehearsals of that mode
+    (gpurun_out/r04_evidence.log, round 4): the process group's watchdog thread queried an event `last recorded in a capturing
+    stream` (hipErrorCapturedEvent) and tore the process down with SIGABRT.  Two precautions, neither proven sufficient: no
+    re-use of the process group's events through its cache, and (train_common.GraphedStep) a pause between the eager warm-up and
+    the capture so that the watchdog has retired every eager collective before the first captured one is issued."""
+    if os.environ.get("FACL_DP_GRAPH", "segments") == "full":
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 
 class CaptureAborted(RuntimeError):

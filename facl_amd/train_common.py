@@ -303,6 +303,10 @@ class GraphedStep:
             # joins a stream capture the way it does on NCCL), so the data-parallel step has no cut at all.  Rehearsed with a
             # 1-rank RCCL group only (bench.py --rehearse-dp 1); with N > 1 ranks it has never run: the validation below
             # (eager step == replayed step, voted across ranks) is what stands between a wrong replay and the measurement.
+            # (facl_amd/dist.py: full_graph_env -- the watchdog must have retired the warm-up's eager collectives before a
+            # captured one is issued: it polls every ~100 ms)
+            import time
+            time.sleep(0.5)
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph, stream=s):

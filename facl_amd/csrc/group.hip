@@ -20,7 +20,7 @@ __device__ __forceinline__ float dist2_exact(float px, float py, float pz, float
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-template <int D, int NPL, int CPW = CENTROIDS_PER_WG>
+template <int D, int NPL, int CPW = CENTROIDS_PER_WG, bool FULL = false>
 __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict__ points, int N, int S,
                                                          int K, float r2, int32_t* __restrict__ idx_out,
                                                          float* __restrict__ xt_out, float* __restrict__ yt_out,
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane;
-            key[j] = (i < N) ? __float_as_uint(dist2_exact(xs[i], ys[i], zs[i], cx, cy, cz)) : 0x7F800000u;
+            // FULL (N == 64 * NPL, the headline's 2048): no padding keys, no compare / select per key
+            key[j] = (FULL || i < N) ? __float_as_uint(dist2_exact(xs[i], ys[i], zs[i], cx, cy, cz)) : 0x7F800000u;
         }
 
         // radix select on the float bit patterns (non-negative floats order like their bits), MSB first.
@@ -222,6 +223,8 @@ int launch_group(const float* points, int M, int N, int S, int K, float r2, int3
         hipLaunchKernelGGL((k_group<D, NPL, 4>), dim3((S + 3) / 4, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
     } else if (cpw == 64) {
         hipLaunchKernelGGL((k_group<D, NPL, 64>), dim3((S + 63) / 64, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
+    } else if (N == 64 * NPL) {
+        hipLaunchKernelGGL((k_group<D, NPL, CENTROIDS_PER_WG, true>), dim3((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
     } else {
         hipLaunchKernelGGL((k_group<D, NPL>), dim3((S + CENTROIDS_PER_WG - 1) / CENTROIDS_PER_WG, M), dim3(GROUP_THREADS), lds, st, points, N, S, K, r2, idx, xt, yt, clipB);
     }

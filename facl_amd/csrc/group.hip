@@ -13,6 +13,9 @@ namespace {
 constexpr int GROUP_THREADS = 256;           // 4 waves
 constexpr int CENTROIDS_PER_WG = 16;         // 4 per wave (the default; the kernel takes the count as a template argument)
 constexpr int CKEYS = 4;                     // keys per lane once the candidate set fits (radix select, second phase)
+constexpr int CKE = 8;                       // K <= 256: entries per lane of the compacted list (keys under the candidate range's top)
+constexpr int CAP = 64 * CKE;                // capacity of that list (per wave: CAP keys + CAP 16-bit indices in LDS)
+constexpr int SLOT_BYTES = CAP * 6;          // per wave: the compacted list; its first words are re-used as the emission slot
 
 // dist^2 exactly as the reference's fp32 chain: (dx*dx + dy*dy) + dz*dz, no FMA contraction.
 __device__ __forceinline__ float dist2_exact(float px, float py, float pz, float cx, float cy, float cz) {
@@ -102,6 +105,111 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                 eguess = e;
             }
         }
+        if (K <= 256) {
+            // ---- K <= 256 (round 4): ONE pass over the registers, then everything on a compacted list ------------------------
+            // Full-width rounds only until the keys under the TOP of the candidate range (the `below` kept ones and the `cand`
+            // candidates) fit the per-wave list: CAP entries, i.e. normally none after the exponent bucket.  The list holds
+            // (key, index) in ascending index order, so the remaining select rounds AND the emission walk <= CKE entries per
+            // lane instead of NPL registers per lane twice (candidate gather + emission pass: ~450 of the ~1,100 vector
+            // instructions per centroid of the previous form).
+            for (; bit >= 0 && cand != K - below && below + cand > CAP; --bit) {
+                const uint32_t pivot = prefix | (1u << bit);
+                const int c = count_below(pivot);
+                if (c < K) { prefix = pivot; cand -= c - below; below = c; }
+                else cand = c - below;
+                hi = ~((1u << bit) - 1u);
+            }
+        }
+        // (more than CAP entries can only be left when the rounds ran out of bits on a mass of exact ties: the full-width tie
+        // ranking below handles that)
+        if (K <= 256 && below + cand <= CAP) {
+            char* sl = reinterpret_cast<char*>(lds + (size_t)D * N) + SLOT_BYTES * wave;
+            uint32_t* slotk = reinterpret_cast<uint32_t*>(sl);
+            unsigned short* sloti = reinterpret_cast<unsigned short*>(sl + 4 * CAP);
+            int E = 0;
+            {
+                const uint32_t top = hi ? prefix + (~hi + 1u) : 0x80000000u;      // exclusive top of the candidate range
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const bool inc = key[j] < top;
+                    const unsigned long long m = __ballot(inc);
+                    if (inc) {
+                        const int pos = E + __popcll(m & lt);
+                        slotk[pos] = key[j]; sloti[pos] = (unsigned short)(j * 64 + lane);
+                    }
+                    E += __popcll(m);
+                }
+            }
+            // E = below + cand <= CAP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+            uint32_t ck[CKE];
+            int ci[CKE];
+#pragma unroll
+            for (int t = 0; t < CKE; ++t) {
+                const int pp = lane + 64 * t;
+                ck[t] = pp < E ? slotk[pp] : 0xFFFFFFFFu;                          // never under a pivot, never kept
+                ci[t] = pp < E ? (int)sloti[pp] : 0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the list is in registers: its LDS words become the emission slot
+            for (; bit >= 0 && cand != K - below; --bit) {
+                const uint32_t pivot = prefix | (1u << bit);
+                int c = 0;                                      // entries under the pivot (the `below` ones are all of them)
+#pragma unroll
+                for (int t = 0; t < CKE; ++t)
+                    if (64 * t < E) c += __popcll(__ballot(ck[t] < pivot));
+                if (c < K) { prefix = pivot; cand -= c - below; below = c; }
+                else cand = c - below;
+                hi = ~((1u << bit) - 1u);
+            }
+            const int remaining = K - below;
+            uint32_t* es = slotk;                               // K <= 256 words
+            int base = 0;
+            if (cand == remaining) {
+                const uint32_t upper = hi ? prefix + (~hi + 1u) : 0x80000000u;
+#pragma unroll
+                for (int t = 0; t < CKE; ++t) {
+                    if (64 * t >= E) break;
+                    const bool take = ck[t] < upper;
+                    const unsigned long long tm = __ballot(take);
+                    if (take) es[base + __popcll(tm & lt)] = (uint32_t)ci[t];
+                    base += __popcll(tm);
+                }
+            } else {                                            // exact ties at the K-th value: the first `remaining` in index order
+                int eq_taken = 0;
+#pragma unroll
+                for (int t = 0; t < CKE; ++t) {
+                    if (64 * t >= E) break;
+                    const uint32_t kh = ck[t] & hi;
+                    const bool is_eq = kh == prefix && lane + 64 * t < E;
+                    const unsigned long long eqm = __ballot(is_eq);
+                    const int eq_rank = eq_taken + __popcll(eqm & lt);
+                    eq_taken += __popcll(eqm);
+                    const bool take = (kh < prefix) || (is_eq && eq_rank < remaining);
+                    const unsigned long long tm = __ballot(take);
+                    if (take) es[base + __popcll(tm & lt)] = (uint32_t)ci[t];
+                    base += __popcll(tm);
+                }
+            }
+            const size_t grp = (size_t)m * S + c;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+            for (int pos = lane; pos < K; pos += 64) {
+                const int i = (int)es[pos];
+                const float px = xs[i], py = ys[i], pz = zs[i];
+                const bool outside = dist2_exact(px, py, pz, cx, cy, cz) > r2;              // strict >, utils_my.py:272
+                const int id = outside ? c : i;
+                const size_t o = grp * K + pos;
+                if (idx_out) idx_out[o] = id;
+                if (xt_out) {
+                    const float gx = outside ? 0.f : __fsub_rn(px, cx), gy = outside ? 0.f : __fsub_rn(py, cy);
+                    const float gz = outside ? 0.f : __fsub_rn(pz, cz);
+                    if (D == 4) *reinterpret_cast<float4*>(xt_out + o * 4) = make_float4(gx, gy, gz, cs[id]);
+                    else { xt_out[o * 3 + 0] = gx; xt_out[o * 3 + 1] = gy; xt_out[o * 3 + 2] = gz; }
+                }
+            }
+            asm volatile("" ::: "memory");                      // the slot is rewritten by the next centroid
+            if (yt_out && lane < 3) yt_out[grp * 3 + lane] = (lane == 0) ? cx : (lane == 1) ? cy : cz;
+            continue;
+        }
         for (; bit >= 0 && cand != K - below && cand > 64 * CKEYS; --bit) {
             const uint32_t pivot = prefix | (1u << bit);
             const int c = count_below(pivot);
@@ -115,7 +223,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             // them into CKEYS keys per lane through a small LDS slot and finish the remaining rounds -- typically half
             // of them -- on those registers instead of walking all NPL.  Only prefix / hi / remaining come out of it;
             // the emission below still uses the original registers, so no index bookkeeping is needed.
-            uint32_t* slot = reinterpret_cast<uint32_t*>(lds) + 4 * N + 64 * CKEYS * wave;
+            uint32_t* slot = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + (size_t)D * N) + SLOT_BYTES * wave);
             int base = 0;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
@@ -149,7 +257,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         // prefix-popcount positions; ~K/NPL lanes are active per pass), then ALL K neighbours are gathered, radius-tested
         // (the distance is recomputed from the coordinates the gather reads anyway: same exact arithmetic), centred and
         // stored by K lanes at once -- K/64 full-width store passes per output instead of NPL passes of a few lanes each.
-        uint32_t* eslot = reinterpret_cast<uint32_t*>(lds) + 4 * N + 64 * CKEYS * wave;      // 256 words per wave
+        uint32_t* eslot = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + (size_t)D * N) + SLOT_BYTES * wave);      // >= 256 words per wave
         // the direct form of one kept neighbour (index i, output slot pos): radius rule, gather, centre, store
         auto emit = [&](int i, int pos) {
             const float px = xs[i], py = ys[i], pz = zs[i];
@@ -212,7 +320,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
 template <int D, int NPL>
 int launch_group(const float* points, int M, int N, int S, int K, float r2, int32_t* idx, float* xt, float* yt,
                  int clipB, hipStream_t st) {
-    const size_t lds = (size_t)N * 4 * sizeof(float) + 4 * 64 * CKEYS * sizeof(uint32_t);   // cloud (SoA) + one key / emission slot per wave
+    const size_t lds = (size_t)N * D * sizeof(float) + 4 * SLOT_BYTES;   // cloud (SoA, D arrays) + one compacted-list / emission slot per wave
     // centroids per workgroup (A/B knob FACL_GROUP_CPW: 16 = four workgroups stage each cloud, 32 = two, 64 = one)
     static const int cpw = getenv("FACL_GROUP_CPW") ? atoi(getenv("FACL_GROUP_CPW")) : CENTROIDS_PER_WG;
     if (cpw == 32) {

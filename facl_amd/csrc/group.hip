@@ -13,14 +13,20 @@ namespace {
 constexpr int GROUP_THREADS = 256;           // 4 waves
 constexpr int CENTROIDS_PER_WG = 16;         // 4 per wave (the default; the kernel takes the count as a template argument)
 constexpr int CKEYS = 4;                     // keys per lane once the candidate set fits (radix select, second phase)
-constexpr int CKE = 8;                       // K <= 256: entries per lane of the compacted list (keys under the candidate range's top)
-constexpr int CAP = 64 * CKE;                // capacity of that list (per wave: CAP keys + CAP 16-bit indices in LDS)
-constexpr int SLOT_BYTES = CAP * 6;          // per wave: the compacted list; its first words are re-used as the emission slot
+constexpr int CKE = 7;                       // K <= 256: entries per lane of the compacted list (keys under the candidate range's top)
+constexpr int CAP = 64 * CKE;                // capacity of that list (per wave: CAP (key, index) pairs of 8 bytes in LDS)
+constexpr int SLOT_BYTES = CAP * 8;          // per wave: the compacted list; its first words are re-used as the emission slot
 
 // dist^2 exactly as the reference's fp32 chain: (dx*dx + dy*dy) + dz*dz, no FMA contraction.
 __device__ __forceinline__ float dist2_exact(float px, float py, float pz, float cx, float cy, float cz) {
     const float dx = __fsub_rn(px, cx), dy = __fsub_rn(py, cy), dz = __fsub_rn(pz, cz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// base + (set bits of mask m below this lane): the hardware's masked bit count, two instructions with the base folded in
+// (`base + __popcll(m & lanemask_lt)` compiles to two ands, two v_bcnt and an add)
+__device__ __forceinline__ int rank_below(unsigned long long m, int base) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
 }
 
 template <int D, int NPL, int CPW = CENTROIDS_PER_WG, bool FULL = false>
@@ -124,8 +130,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         // ranking below handles that)
         if (K <= 256 && below + cand <= CAP) {
             char* sl = reinterpret_cast<char*>(lds + (size_t)D * N) + SLOT_BYTES * wave;
-            uint32_t* slotk = reinterpret_cast<uint32_t*>(sl);
-            unsigned short* sloti = reinterpret_cast<unsigned short*>(sl + 4 * CAP);
+            uint2* slotp = reinterpret_cast<uint2*>(sl);        // (key, index): one 8-byte store / load per entry
             int E = 0;
             {
                 const uint32_t top = hi ? prefix + (~hi + 1u) : 0x80000000u;      // exclusive top of the candidate range
@@ -134,8 +139,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                     const bool inc = key[j] < top;
                     const unsigned long long m = __ballot(inc);
                     if (inc) {
-                        const int pos = E + __popcll(m & lt);
-                        slotk[pos] = key[j]; sloti[pos] = (unsigned short)(j * 64 + lane);
+                        slotp[rank_below(m, E)] = make_uint2(key[j], (uint32_t)(j * 64 + lane));
                     }
                     E += __popcll(m);
                 }
@@ -147,8 +151,9 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
 #pragma unroll
             for (int t = 0; t < CKE; ++t) {
                 const int pp = lane + 64 * t;
-                ck[t] = pp < E ? slotk[pp] : 0xFFFFFFFFu;                          // never under a pivot, never kept
-                ci[t] = pp < E ? (int)sloti[pp] : 0;
+                const uint2 e = pp < E ? slotp[pp] : make_uint2(0xFFFFFFFFu, 0u);   // padding: never under a pivot, never kept
+                ck[t] = e.x;
+                ci[t] = (int)e.y;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the list is in registers: its LDS words become the emission slot
             for (; bit >= 0 && cand != K - below; --bit) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                 hi = ~((1u << bit) - 1u);
             }
             const int remaining = K - below;
-            uint32_t* es = slotk;                               // K <= 256 words
+            uint32_t* es = reinterpret_cast<uint32_t*>(sl);     // K <= 256 words
             int base = 0;
             if (cand == remaining) {
                 const uint32_t upper = hi ? prefix + (~hi + 1u) : 0x80000000u;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                     if (64 * t >= E) break;
                     const bool take = ck[t] < upper;
                     const unsigned long long tm = __ballot(take);
-                    if (take) es[base + __popcll(tm & lt)] = (uint32_t)ci[t];
+                    if (take) es[rank_below(tm, base)] = (uint32_t)ci[t];
                     base += __popcll(tm);
                 }
             } else {                                            // exact ties at the K-th value: the first `remaining` in index order
@@ -182,11 +187,11 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                     const uint32_t kh = ck[t] & hi;
                     const bool is_eq = kh == prefix && lane + 64 * t < E;
                     const unsigned long long eqm = __ballot(is_eq);
-                    const int eq_rank = eq_taken + __popcll(eqm & lt);
+                    const int eq_rank = rank_below(eqm, eq_taken);
                     eq_taken += __popcll(eqm);
                     const bool take = (kh < prefix) || (is_eq && eq_rank < remaining);
                     const unsigned long long tm = __ballot(take);
-                    if (take) es[base + __popcll(tm & lt)] = (uint32_t)ci[t];
+                    if (take) es[rank_below(tm, base)] = (uint32_t)ci[t];
                     base += __popcll(tm);
                 }
             }
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
             for (int j = 0; j < NPL; ++j) {
                 const bool isc = (key[j] & hi) == prefix;
                 const unsigned long long m = __ballot(isc);
-                if (isc) slot[base + __popcll(m & lt)] = key[j];
+                if (isc) slot[rank_below(m, base)] = key[j];
                 base += __popcll(m);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                 const bool take = key[j] < upper;
                 const unsigned long long tm = __ballot(take);
                 if (take) {
-                    const int pos = base + __popcll(tm & lt);
+                    const int pos = rank_below(tm, base);
                     if (K <= 256) eslot[pos] = (uint32_t)(j * 64 + lane);
                     else emit(j * 64 + lane, pos);
                 }
@@ -296,12 +301,12 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                 const uint32_t kh = key[j] & hi;
                 const bool is_eq = kh == prefix;
                 const unsigned long long eqm = __ballot(is_eq);
-                const int eq_rank = eq_taken + __popcll(eqm & lt);
+                const int eq_rank = rank_below(eqm, eq_taken);
                 eq_taken += __popcll(eqm);
                 const bool take = (kh < prefix) || (is_eq && eq_rank < remaining);
                 const unsigned long long tm = __ballot(take);
                 if (take) {
-                    const int pos = base + __popcll(tm & lt);
+                    const int pos = rank_below(tm, base);
                     if (K <= 256) eslot[pos] = (uint32_t)(j * 64 + lane);
                     else emit(j * 64 + lane, pos);
                 }

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
     __syncthreads();
 
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the per-wave LDS slot's address stays scalar
     const unsigned long long lt = lanemask_lt();
 
     uint32_t eguess = 122;                    // wave-persistent exponent guess of the K-th distance^2 (2^-5 .. 2^-4 to start with)
@@ -139,7 +139,12 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
                     const bool inc = key[j] < top;
                     const unsigned long long m = __ballot(inc);
                     if (inc) {
-                        slotp[rank_below(m, E)] = make_uint2(key[j], (uint32_t)(j * 64 + lane));
+                        // two dword stores (ds_write2_b32): an 8-byte store needs key and index in a register PAIR, i.e. a copy
+                        // per entry into a pair the previous store may still be reading (an lgkmcnt wait every other entry)
+                        // (the running entry count stays on the scalar side: folded into the store's base address, not into the rank)
+                        uint32_t* e2 = reinterpret_cast<uint32_t*>(slotp + E) + 2 * rank_below(m, 0);
+                        e2[0] = key[j];
+                        e2[1] = (uint32_t)(j * 64 + lane);
                     }
                     E += __popcll(m);
                 }

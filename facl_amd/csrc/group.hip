@@ -69,11 +69,19 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
         const float cx = xs[c], cy = ys[c], cz = zs[c];
 
         uint32_t key[NPL];
+        // Two keys per packed instruction, written as 2-vectors in the order the paired LDS reads deliver them (left to the
+        // vectoriser the same packing came with six register moves per pair: the pair order reversed).  Same arithmetic as
+        // dist2_exact -- (dx*dx + dy*dy) + dz*dz, every operation rounded, nothing fused (the file is built with contraction off).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int i = j * 64 + lane;
+        for (int j = 0; j < NPL; j += 2) {
+            const int i0 = j * 64 + lane, i1 = i0 + 64;
+            const f32x2 px = {xs[i0], xs[i1]}, py = {ys[i0], ys[i1]}, pz = {zs[i0], zs[i1]};
+            const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
             // FULL (N == 64 * NPL, the headline's 2048): no padding keys, no compare / select per key
-            key[j] = (FULL || i < N) ? __float_as_uint(dist2_exact(xs[i], ys[i], zs[i], cx, cy, cz)) : 0x7F800000u;
+            key[j] = (FULL || i0 < N) ? __float_as_uint(d.x) : 0x7F800000u;
+            key[j + 1] = (FULL || i1 < N) ? __float_as_uint(d.y) : 0x7F800000u;
         }
 
         // radix select on the float bit patterns (non-negative floats order like their bits), MSB first.

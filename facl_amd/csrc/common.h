@@ -211,6 +211,19 @@ __device__ __forceinline__ int h3_se_wide(unsigned b) {
     return se < 47 ? 47 : se;
 }
 __device__ __forceinline__ float pow2_biased(int e) { return __uint_as_float((unsigned)e << 23); }
+// maximum of a non-negative value over the wave on the DPP crossbar (row_shr 1,2,4,8, row_bcast 15 / 31; no LDS round trip),
+// uniform result
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float facl_dpp_max_step(float v) {
+    const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false);
+    return fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ __forceinline__ float facl_wave_max_nonneg(float v) {
+    v = facl_dpp_max_step<0x111, 0xf>(v); v = facl_dpp_max_step<0x112, 0xf>(v); v = facl_dpp_max_step<0x114, 0xf>(v);
+    v = facl_dpp_max_step<0x118, 0xf>(v); v = facl_dpp_max_step<0x142, 0xa>(v); v = facl_dpp_max_step<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // 1 / (2^(seA-127) 2^(seB-127)): biased exponent 381 - seA - seB (two narrow scales: [47, 207]; one wide: [7, 247])
 __device__ __forceinline__ float h3_unscale(int seA, int seB) { return pow2_biased(381 - seA - seB); }
 // wave-uniform maximum over the FACL_AMAX_SLOTS slots of an amax buffer (rows.hip: abs_max_slot writes them)

@@ -584,7 +584,7 @@ __device__ __forceinline__ void write_tile_ic8(unsigned short* __restrict__ S, c
 
 template <bool PRO, int T, int NP>
 __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigned (&pk)[12 * T], int tid, int k0,
-                                               const float* __restrict__ ps, const float* __restrict__ pt) {
+                                               const float* __restrict__ ps, const float* __restrict__ pt, float sc = 1.f) {
 #pragma unroll
     for (int i = 0; i < 2 * T; ++i) {
         float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
@@ -595,7 +595,10 @@ __device__ __forceinline__ void split_tile_kc4(const float4 (&r)[2 * T], unsigne
             v[0] = relu_nan(fmaf(s.x, v[0], t.x)); v[1] = relu_nan(fmaf(s.y, v[1], t.y));
             v[2] = relu_nan(fmaf(s.z, v[2], t.z)); v[3] = relu_nan(fmaf(s.w, v[3], t.w));
         }
-        if (NP >= 2) {
+        if (NP == 4) {                                                  // fp16x3: two fp16 planes of x * sc
+            split_pair_h(v[0] * sc, v[1] * sc, pk[6 * i], pk[6 * i + 2]);
+            split_pair_h(v[2] * sc, v[3] * sc, pk[6 * i + 1], pk[6 * i + 3]);
+        } else if (NP >= 2) {
             split_pair(v[0], v[1], pk[6 * i], pk[6 * i + 2], pk[6 * i + 4]);
             split_pair(v[2], v[3], pk[6 * i + 1], pk[6 * i + 3], pk[6 * i + 5]);
         } else {
@@ -611,7 +614,7 @@ __device__ __forceinline__ void write_tile_kc4(unsigned short* __restrict__ S, c
     for (int i = 0; i < 2 * T; ++i) {
         unsigned short* d = S + ((tid >> 3) + 32 * i) * SBROW + 4 * (tid & 7);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + p * PLANE) = make_uint2(pk[6 * i + 2 * p], pk[6 * i + 2 * p + 1]);
+        for (int p = 0; p < (NP == 4 ? 2 : NP); ++p) *reinterpret_cast<uint2*>(d + p * PLANE) = make_uint2(pk[6 * i + 2 * p], pk[6 * i + 2 * p + 1]);
     }
 }
 
@@ -764,15 +767,23 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void k_gemm_sb(GemmArgs g) {
 // ordinary epilogue, so bias / statistics / centre term keep working and no slice buffer or second kernel is needed.
 template <int LA, int LB, bool PRO, int NP, int KG>
 __global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
+    // NP = 4 ("self-scaled fp16x3", round 4, PRO = false only): two fp16 planes per operand and three products per stage, each
+    // STAGE (a 64 x 32 tile of A and of B, one group's work) scaled by the power of two of its OWN maximum -- no operand scale
+    // comes in from outside -- and its 32-deep partial product added to the accumulator with the exact inverse.  These kernels
+    // are bound by their split + MFMA instructions: 6 instead of 11 vector instructions per operand pair, 6
+    // instead of 12 MFMAs per stage.  A tile-local scale is at least as fine as a tensor-wide one (tile maximum <= tensor maximum).
+    constexpr int NPL = NP == 4 ? 2 : NP;                               // planes per operand in LDS
     constexpr int PL = 64 * SBROW;                                      // one plane of one operand (elements)
-    constexpr int TILE_F = NP * 2 * PL * 2 / 4;                         // both operand images of a group, in floats
+    constexpr int TILE_F = NPL * 2 * PL * 2 / 4;                        // both operand images of a group, in floats
     constexpr int STG = 4 * 32 * 36;                                    // epilogue staging of group 0 (floats)
+    constexpr int MXOFF = KG * TILE_F > STG + (KG - 1) * 4096 ? KG * TILE_F : STG + (KG - 1) * 4096;   // [KG][4][2] stage maxima behind everything
+    static_assert(NP != 4 || !PRO, "the self-scaled form takes the maximum of the raw registers: no prologue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     unsigned short* const sA = reinterpret_cast<unsigned short*>(smem + grp * TILE_F);
-    unsigned short* const sB = sA + NP * PL;
+    unsigned short* const sB = sA + NPL * PL;
     const TileId tile = xcd_tile();
     const int i0 = tile.y * 64, j0 = tile.x * 64;
     const int kbeg = tile.z * g.kchunk;
@@ -799,11 +810,42 @@ __global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
         }
     };
     unsigned pka[12], pkb[12];
+    float* const mxs = smem + MXOFF;
+    float uns_nxt = 1.f;                                                // NP = 4: inverse scale of the stage `split` has just prepared
     auto split = [&](int k0) {
-        if (LA == KC) split_tile_kc4<PRO, 1, NP>(ra4, pka, tid, k0, g.pscale, g.pshift);
-        else split_tile_ic8<1, NP>(ra8, pka);
-        if (LB == KC) split_tile_kc4<false, 1, NP>(rb4, pkb, tid, k0, nullptr, nullptr);
-        else split_tile_ic8<1, NP>(rb8, pkb);
+        float sca = 1.f, scb = 1.f;
+        if constexpr (NP == 4) {
+            // maxima of the group's raw stage tiles: registers -> wave (DPP) -> the group's four waves (LDS, behind a workgroup
+            // barrier that ALSO is the one after which the current LDS tile may be overwritten: every wave's MFMA reads are done)
+            float ma = 0.f, mb = 0.f;
+            if (LA == KC) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ma = fmaxf(fmaxf(ma, fmaxf(fabsf(ra4[i].x), fabsf(ra4[i].y))), fmaxf(fabsf(ra4[i].z), fabsf(ra4[i].w)));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ma = fmaxf(ma, fabsf(ra8[i]));
+            }
+            if (LB == KC) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) mb = fmaxf(fmaxf(mb, fmaxf(fabsf(rb4[i].x), fabsf(rb4[i].y))), fmaxf(fabsf(rb4[i].z), fabsf(rb4[i].w)));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mb = fmaxf(mb, fabsf(rb8[i]));
+            }
+            ma = facl_wave_max_nonneg(ma); mb = facl_wave_max_nonneg(mb);
+            if (lane == 0) { mxs[(grp * 4 + wave) * 2] = ma; mxs[(grp * 4 + wave) * 2 + 1] = mb; }
+            __syncthreads();
+            const float4 m01 = *reinterpret_cast<const float4*>(mxs + grp * 8), m23 = *reinterpret_cast<const float4*>(mxs + grp * 8 + 4);
+            ma = fmaxf(fmaxf(m01.x, m01.z), fmaxf(m23.x, m23.z));
+            mb = fmaxf(fmaxf(m01.y, m01.w), fmaxf(m23.y, m23.w));
+            const int seA = h3_se(__float_as_uint(ma)), seB = h3_se(__float_as_uint(mb));      // NaN / inf pass through as such
+            sca = pow2_biased(seA); scb = pow2_biased(seB);
+            uns_nxt = h3_unscale(seA, seB);
+        }
+        if (LA == KC) split_tile_kc4<PRO, 1, NP>(ra4, pka, tid, k0, g.pscale, g.pshift, sca);
+        else split_tile_ic8<1, NP>(ra8, pka, 1.f, 0.f, sca);
+        if (LB == KC) split_tile_kc4<false, 1, NP>(rb4, pkb, tid, k0, nullptr, nullptr, scb);
+        else split_tile_ic8<1, NP>(rb8, pkb, 1.f, 0.f, scb);
     };
     auto write = [&]() {
         if (LA == KC) write_tile_kc4<1, NP>(sA, pka, tid);
@@ -811,14 +853,19 @@ __global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
         if (LB == KC) write_tile_kc4<1, NP>(sB, pkb, tid);
         else write_tile_ic8<1, NP>(sB, pkb, tid);
     };
+    f32x16 stg_acc;                                                     // NP = 4: the current stage's partial product (scaled)
     auto mfma_block = [&](int kk) {
-        bf16x8 af[NP], bf[NP];
+        bf16x8 af[NPL], bf[NPL];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NPL; ++p) {
             af[p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + (32 * wr + q) * SBROW + 16 * kk + 8 * h);
             bf[p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + (32 * wc + q) * SBROW + 16 * kk + 8 * h);
         }
-        if constexpr (NP == 1) {
+        if constexpr (NP == 4) {                                        // smallest terms first: (lo,hi) (hi,lo) (hi,hi)
+            const f16x8h a0 = __builtin_bit_cast(f16x8h, af[0]), a1 = __builtin_bit_cast(f16x8h, af[1]);
+            const f16x8h b0 = __builtin_bit_cast(f16x8h, bf[0]), b1 = __builtin_bit_cast(f16x8h, bf[1]);
+            stg_acc = MFMA_F16(a1, b0, stg_acc); stg_acc = MFMA_F16(a0, b1, stg_acc); stg_acc = MFMA_F16(a0, b0, stg_acc);
+        } else if constexpr (NP == 1) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]),
                                                                acc[0][0], 0, 0, 0);
         } else {
@@ -837,17 +884,27 @@ __global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
     };
     { const int k0 = kof(0); fetch(k0); split(k0); write(); }
     __syncthreads();
+    float uns_cur = uns_nxt;                                            // NP = 4: inverse scale of the stage now in LDS
     for (int it = 0; it < nit; ++it) {
         const int kn = kof(it + 1 < nit ? it + 1 : it);
         fetch(kn);
         if (grp + KG * it < nst) {                                     // wave-uniform
+            if constexpr (NP == 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg_acc[r] = 0.f;
+            }
             mfma_block(0);
             mfma_block(1);
+            if constexpr (NP == 4) {                                    // exact rescale (a power of two), then the ordinary fp32 add
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] = fmaf(stg_acc[r], uns_cur, acc[0][0][r]);
+            }
         }
-        split(kn);
-        __syncthreads();
+        split(kn);                                                      // (NP = 4: holds the barrier behind the MFMA reads)
+        if constexpr (NP != 4) __syncthreads();
         write();
         __syncthreads();
+        uns_cur = uns_nxt;
     }
     // partial tiles -> LDS (behind group 0's staging area), summed by group 0 in group order
     float* red = smem + STG;
@@ -867,9 +924,9 @@ __global__ __launch_bounds__(256 * KG, 1) void k_gemm_sbk(GemmArgs g) {
 constexpr int SBK_KG = 4;
 template <int LA, int LB, bool PRO, int NP>
 int launch_sbk(const GemmArgs& g, int nz, hipStream_t st) {
-    constexpr int TILE_F = NP * 2 * 64 * SBROW * 2 / 4, STG = 4 * 32 * 36;
+    constexpr int TILE_F = (NP == 4 ? 2 : NP) * 2 * 64 * SBROW * 2 / 4, STG = 4 * 32 * 36;
     constexpr int F = SBK_KG * TILE_F > STG + (SBK_KG - 1) * 4096 ? SBK_KG * TILE_F : STG + (SBK_KG - 1) * 4096;
-    constexpr int lds = F * 4;
+    constexpr int lds = (F + SBK_KG * 8) * 4;                           // + the stage maxima of the self-scaled form
     static bool attr_done[64] = {};                   // per template instantiation and device ordinal
     const void* fns[1] = {(const void*)k_gemm_sbk<LA, LB, PRO, NP, SBK_KG>};
     if (int rc = facl_set_dynamic_lds(attr_done, fns, 1, lds)) return rc;
@@ -987,6 +1044,13 @@ int launch(const GemmArgs& g, int nz, hipStream_t st, int* rows_per_part) {
     if (!use_f32) {
         if (sbk_fits(g, nz)) {
             if (rows_per_part) *rows_per_part = 32;
+            // OPT-IN FACL_SBK_H3=1: self-scaled fp16x3 (k_gemm_sbk, NP = 4; not with a prologue).  Measured inside the step: 2.938 vs
+            // 2.946 ms (gpurun_out/r7b_ab.log), stand-alone -7..-9 % at K = 1024 -- the split is ~20 % cheaper, not 2.7x: the maximum
+            // exchange, the per-stage rescale and the accumulator reset take back most of what the shorter split gives.  Default: bf16x6.
+            static const int sbk_h3 = getenv("FACL_SBK_H3") ? atoi(getenv("FACL_SBK_H3")) : 0;
+            if constexpr (!PRO) {
+                if (sbk_h3) return launch_sbk<LA, LB, false, 4>(g, nz, st);
+            }
             return launch_sbk<LA, LB, PRO, 3>(g, nz, st);
         }
         if (big >= 256) {

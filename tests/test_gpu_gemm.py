@@ -86,6 +86,49 @@ def test_gemm_wgrad(M, N, K, nz):
     assert rel_err(dW.cpu().numpy(), ref.cpu().numpy()) < 3e-6
 
 
+_SBK_H3_CHILD = r"""
+import sys, torch
+sys.path.insert(0, ".")
+from facl_amd import _lib
+lib = _lib.load_library(); p = _lib.ptr; dev = torch.device("cuda:0")
+from facl_amd.sa_mlp import _Workspace
+ws = _Workspace.get(dev)
+worst = 0.0
+def rel(x, ref): return float((x.double() - ref).abs().max() / ref.abs().max())
+g = torch.Generator(device=dev).manual_seed(3)
+for M, K, N, mag_a, mag_w in ((800, 1024, 1024, 1.0, 0.03), (800, 1000, 512, 3e-6, 40.0), (80, 260, 500, 2e4, 1e-5), (768, 512, 768, 1.0, 1.0)):
+    a = torch.randn(M, K, device=dev, generator=g) * mag_a
+    a[:, : K // 2] *= 1e-3                                   # stages of very different magnitude inside one contraction
+    W = torch.randn(N, K, device=dev, generator=g) * mag_w
+    b = torch.randn(N, device=dev, generator=g) * mag_a * mag_w
+    y = torch.full((M, N), float("nan"), device=dev)
+    _lib.check(lib.facl_gemm_fwd(p(a), M, K, p(W), K, N, p(b), None, None, None, None, 0, p(y), None, p(ws), _lib.stream()), "fwd")
+    worst = max(worst, rel(y, a.double() @ W.double().t() + b.double()))
+    dy = torch.randn(M, N, device=dev, generator=g) * 1e-4
+    da = torch.full((M, K), float("nan"), device=dev)
+    _lib.check(lib.facl_gemm_dgrad(p(dy), M, N, p(W), K, K, p(da), _lib.stream()), "dgrad")
+    worst = max(worst, rel(da, dy.double() @ W.double()))
+    dW = torch.full((N, K), float("nan"), device=dev); sl = torch.empty(N * K, device=dev)
+    _lib.check(lib.facl_gemm_wgrad(p(dy), p(a), M, N, K, K, p(dW), p(sl), 1, _lib.stream()), "wgrad")
+    worst = max(worst, rel(dW, dy.double().t() @ a.double()))
+print("WORST %.3e" % worst)
+"""
+
+
+def test_few_row_gemms_optin_self_scaled_fp16x3_is_fp32_grade():
+    """OPT-IN FACL_SBK_H3=1 (k_gemm_sbk NP = 4: every 64 x 32 stage scaled by the power of two of its own maximum): forward, dgrad
+    and weight gradient of few-row shapes -- ragged stages, operands of very different and of tiny / huge magnitude -- stay at
+    fp32-GEMM level against fp64.  The switch is read once per process: a child process."""
+    import os, subprocess, sys
+    env = dict(os.environ, FACL_SBK_H3="1")
+    r = subprocess.run([sys.executable, "-c", _SBK_H3_CHILD], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().splitlines()[-1].split()[1])
+    print("self-scaled fp16x3 worst relative error", worst)
+    assert worst < 3e-6
+
+
 @pytest.mark.parametrize("K,N,ctr", [(256, 256, True), (256, 512, False), (512, 1024, False)])
 def test_tail_layers_headline_size_vs_torch_fp64(K, N, ctr):
     """The three net3DV_3 layers at the headline row count (B*T*S = 49,152 centroid rows) through the Python wrappers the

@@ -60,7 +60,6 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group(const float* __restrict
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the per-wave LDS slot's address stays scalar
-    const unsigned long long lt = lanemask_lt();
 
     uint32_t eguess = 122;                    // wave-persistent exponent guess of the K-th distance^2 (2^-5 .. 2^-4 to start with)
     for (int ci = wave; ci < CPW; ci += GROUP_THREADS / 64) {

@@ -1,3 +1,4 @@
+// build + run on a GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/l2bw tools/probe_l2bw.hip && /tmp/l2bw   (output of round 4: profiles/r04_probe_l2bw.txt)
 // per-CU fill bandwidth probe: each workgroup re-reads a region of `region` bytes `iters` times with 16-byte loads, DEPTH loads in flight per thread
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -41,6 +41,7 @@ SIGNATURES = {
     "facl_bn_eval_consts": [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p],
     "facl_sa_x_moments": [c_p, c_l, c_i, c_p, c_p, c_p],
     "facl_bn1_sums_from_moments": [c_p, c_d, c_i, c_p, c_p, c_p, c_p],
+    "facl_sa_bn1_chain": [c_p, c_d, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_l1tab": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd2": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "facl_sa_fwd3": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],

@@ -183,6 +183,59 @@ __global__ void k_bn1_sums_from_moments(const double* __restrict__ mom, double c
     sums[2 * c + 1] = q + 2.0 * b * ws + count * b * b;
 }
 
+// The three steps between the input moments and the layer-1 table in ONE single-wave launch (training, C = 64): the sums of
+// k_bn1_sums_from_moments, the constants / running statistics / activation bound of k_bn_finalize and the folded table of k_l1tab --
+// the same expressions in the same order, so every output is bit-identical to the three-launch chain (2 launches fewer per step).
+__global__ __launch_bounds__(64) void k_sa_bn1_chain(const double* __restrict__ mom, double count, int D,
+                                                     const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     float momentum, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, double* __restrict__ sums,
+                                                     float* __restrict__ bnc, unsigned* __restrict__ aamax, float* __restrict__ tab) {
+    constexpr int C = 64;
+    const int c = threadIdx.x;
+    const double* sx = mom;
+    const double* X2 = mom + D;
+    double ws = 0, q = 0;
+    for (int i = 0; i < D; ++i) {
+        const double wi = W1[c * D + i];
+        ws += wi * sx[i];
+        double t = 0;
+        for (int j = 0; j < D; ++j) t += X2[i * D + j] * (double)W1[c * D + j];
+        q += wi * t;
+    }
+    const double bb = b1[c];
+    const double su = ws + count * bb, sq = q + 2.0 * bb * ws + count * bb * bb;
+    sums[2 * c] = su;
+    sums[2 * c + 1] = sq;
+    const double mean = su / count;
+    double var = sq / count - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma[c], b = beta[c];
+    const float scale = (float)(g * invstd), shift = (float)(b - mean * g * invstd);
+    bnc[0 * C + c] = (float)mean;
+    bnc[1 * C + c] = (float)invstd;
+    bnc[2 * C + c] = scale;
+    bnc[3 * C + c] = shift;
+    bnc[4 * C + c] = g < 0 ? -1.0f : 1.0f;
+    if (running_mean) {
+        const double unb = count > 1 ? var * count / (count - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+    if (aamax) {
+        const double bd = (fabs(g) * sqrt((count > 1 ? count - 1 : 1) * var) * invstd + fabs(b)) * 1.001;
+        float bound = (float)bd;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+        if (threadIdx.x < FACL_AMAX_SLOTS) aamax[threadIdx.x * FACL_AMAX_STRIDE] = __float_as_uint(bound);
+    }
+    for (int i = 0; i < 4; ++i) tab[c * 8 + i] = i < D ? scale * W1[c * D + i] : 0.0f;
+    tab[c * 8 + 4] = scale * b1[c] + shift;
+    tab[c * 8 + 5] = tab[c * 8 + 6] = tab[c * 8 + 7] = 0.0f;
+}
+
 // Fold BN1 into the first 1x1 conv: a1 = relu((scale*W1) x + (scale*b1 + shift)); rows of 8 floats.
 // `xamax` -> `a1amax` (both or neither): with X = max|x| over all coordinates (facl_absmax), |a1_c| <= X sum_i |w'_ci| + |b'_c|:
 // the bound of the layer-1 activation for eval-mode constants (train mode takes BatchNorm's own bound, facl_bn_finalize).
@@ -355,6 +408,16 @@ extern "C" int facl_bn1_sums_from_moments(const double* mom, double count, int D
     if (D != 3 && D != 4) return FACL_E_SHAPE;
     hipLaunchKernelGGL(k_bn1_sums_from_moments, dim3(1), dim3(64), 0, (hipStream_t)stream, mom, count, D, W1, b1, 64,
                        sums);
+    return facl_launch_status();
+}
+
+extern "C" int facl_sa_bn1_chain(const double* mom, double count, int D, const float* W1, const float* b1, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                 double* sums, float* bnc, uint32_t* aamax, float* l1tab, void* stream) {
+    if (!mom || !W1 || !b1 || !gamma || !beta || !sums || !bnc || !l1tab) return FACL_E_NULL;
+    if ((D != 3 && D != 4) || count < 1) return FACL_E_SHAPE;
+    hipLaunchKernelGGL(k_sa_bn1_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, mom, count, D, W1, b1, gamma, beta, eps, momentum,
+                       running_mean, running_var, sums, bnc, aamax, l1tab);
     return facl_launch_status();
 }
 

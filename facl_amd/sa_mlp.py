@@ -142,23 +142,26 @@ def sa_mlp_forward(x_rows, p, training, reduce_fn=None, update_running=True, K=6
             mom = reduce_fn(mom.clone())
             count = float(P) * reduce_fn.world_size          # every rank holds the same number of positions
         sums1 = _lib.empty((64, 2), **f64)
-        _lib.check(lib.facl_bn1_sums_from_moments(_lib.ptr(mom), count, D, _lib.ptr(W1), _lib.ptr(p["b1"]),
-                                                  _lib.ptr(sums1), st), "facl_bn1_sums_from_moments")
         direct = update_running and rep == 1
         n_true = count / rep
         rm, rv = (p["rm1"], p["rv1"]) if direct else (None, None)
-        bnc1 = _bn_finalize(sums1, 64, count, p["g1"], p["be1"], rm, rv, aamax=amax[1])
+        # sums of y1 from the moments -> BatchNorm-1 constants (+ running statistics, + the bound of a1) -> folded layer-1 table:
+        # one single-wave launch (facl_sa_bn1_chain; bit-identical to facl_bn1_sums_from_moments + facl_bn_finalize + facl_sa_l1tab)
+        bnc1 = _lib.empty((5, 64), dtype=torch.float32, device=dev)
+        l1tab = _lib.empty((64, 8), dtype=torch.float32, device=dev)
+        _lib.check(lib.facl_sa_bn1_chain(_lib.ptr(mom), count, D, _lib.ptr(W1), _lib.ptr(p["b1"]), _lib.ptr(p["g1"]), _lib.ptr(p["be1"]),
+                                         BN_EPS, BN_MOMENTUM, _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(sums1), _lib.ptr(bnc1),
+                                         _lib.ptr(amax[1]), _lib.ptr(l1tab), st), "facl_sa_bn1_chain")
         if update_running and not direct:
             _running_update(bnc1, p["rm1"], p["rv1"], n_true)
         ctx["mom"] = mom
-        xa = None
     else:
         bnc1 = _bn_eval(64, p["g1"], p["be1"], p["rm1"], p["rv1"])
         xa = amax[0]                                       # eval: the bound of a1 follows from max|x| (facl_sa_l1tab)
         _lib.check(lib.facl_absmax(_lib.ptr(x_rows), x_rows.numel(), _lib.ptr(xa), st), "facl_absmax")
-    l1tab = _lib.empty((64, 8), dtype=torch.float32, device=dev)
-    _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(p["b1"]), D, _lib.ptr(bnc1[2]), _lib.ptr(bnc1[3]),
-                                 _lib.ptr(l1tab), _lib.ptr(xa), None if xa is None else _lib.ptr(amax[1]), st), "facl_sa_l1tab")
+        l1tab = _lib.empty((64, 8), dtype=torch.float32, device=dev)
+        _lib.check(lib.facl_sa_l1tab(_lib.ptr(W1), _lib.ptr(p["b1"]), D, _lib.ptr(bnc1[2]), _lib.ptr(bnc1[3]),
+                                     _lib.ptr(l1tab), _lib.ptr(xa), _lib.ptr(amax[1]), st), "facl_sa_l1tab")
     if not training and _EVAL_FUSED and precision in ("f32", "x3b") and _FWD_H3:
         # eval mode = the extraction path (extract_motion_feature.py:143-221): every BatchNorm is a constant affine, so the whole
         # block is ONE kernel per unit, x -> pooled, with nothing stored in between (csrc/sa_eval.hip)

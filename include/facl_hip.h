@@ -106,6 +106,11 @@ int facl_bn_eval_consts(int C, const float* gamma, const float* beta, const floa
 int facl_sa_x_moments(const float* x, int64_t P, int D, double* mom, void* ws, void* stream);
 int facl_bn1_sums_from_moments(const double* mom, double count, int D, const float* W1, const float* b1,
                                double* sums, void* stream);
+/* training, the 64-channel first layer: facl_bn1_sums_from_moments + facl_bn_finalize + facl_sa_l1tab in ONE launch (sums (64,2),
+ * bnc (5,64), running statistics, the activation bound in aamax, l1tab (64,8)); every output bit-identical to the three calls */
+int facl_sa_bn1_chain(const double* mom, double count, int D, const float* W1, const float* b1, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      double* sums, float* bnc, uint32_t* aamax, float* l1tab, void* stream);
 /* xamax -> a1amax (both or neither; FACL_AMAX_WORDS uint32 each): the bound of max|a1| from max|x| (eval-mode constants give
  * no bound of their own; in training facl_bn_finalize's aamax of BN1 serves) */
 int facl_sa_l1tab(const float* W1, const float* b1, int D, const float* scale, const float* shift,

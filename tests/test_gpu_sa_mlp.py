@@ -417,3 +417,39 @@ def test_sa_ragged_unit_counts(nunits):
         err = float((mine.grad.double() - g64).norm())
         # tiny batches make train-mode BN ill-conditioned (64 positions at nunits = 1): scaled like the golden tests
         assert err <= tol * max(float(g64.norm()), 1e-2 * gmax), (k, err, float(g64.norm()), flips)
+
+
+@pytest.mark.parametrize("D", [3, 4])
+def test_bn1_chain_equals_its_three_launches_bitwise(D):
+    """facl_sa_bn1_chain (moments -> sums of y1 -> BatchNorm-1 constants, running statistics, activation bound -> folded layer-1
+    table, one launch) against facl_bn1_sums_from_moments + facl_bn_finalize + facl_sa_l1tab: every output bit for bit."""
+    from facl_amd import _lib
+    lib = _lib.load_library()
+    p = _lib.ptr
+    g = torch.Generator(device=DEV).manual_seed(17 + D)
+    P = 50000.0
+    x = torch.randn(4096, D, device=DEV, generator=g, dtype=torch.float64)
+    mom = torch.cat(((x.sum(0) * (P / 4096)), ((x.t() @ x) * (P / 4096)).reshape(-1))).contiguous()
+    W1 = (torch.randn(64, D, device=DEV, generator=g) * 0.5).contiguous()
+    b1 = torch.randn(64, device=DEV, generator=g)
+    gam = torch.randn(64, device=DEV, generator=g)               # negative gammas included
+    bet = torch.randn(64, device=DEV, generator=g)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        sums = torch.full((64, 2), float("nan"), device=DEV, dtype=torch.float64)
+        bnc = torch.full((5, 64), float("nan"), device=DEV)
+        tab = torch.full((64, 8), float("nan"), device=DEV)
+        amax = torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device=DEV)
+        if fused:
+            _lib.check(lib.facl_sa_bn1_chain(p(mom), P, D, p(W1), p(b1), p(gam), p(bet), 1e-5, 0.1, p(rm), p(rv), p(sums), p(bnc),
+                                             p(amax), p(tab), _lib.stream()), "chain")
+        else:
+            _lib.check(lib.facl_bn1_sums_from_moments(p(mom), P, D, p(W1), p(b1), p(sums), _lib.stream()), "sums")
+            _lib.check(lib.facl_bn_finalize(p(sums), 64, P, p(gam), p(bet), 1e-5, 0.1, p(rm), p(rv), p(bnc), p(amax), None,
+                                            _lib.stream()), "finalize")
+            _lib.check(lib.facl_sa_l1tab(p(W1), p(b1), D, p(bnc[2]), p(bnc[3]), p(tab), None, None, _lib.stream()), "l1tab")
+        outs.append((sums, bnc, tab, rm, rv, amax))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[1][1]).all() and torch.isfinite(outs[1][2]).all()

@@ -56,7 +56,7 @@ SIGNATURES = {
     "facl_rows_bwd_apply": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     "facl_rows_bwd_apply_amax": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_segmax_bwd_stats": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
-    "facl_segmax_bwd_stats_ymax": [c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "facl_segmax_bwd_stats_ymax": [c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     "facl_segmax_bwd_apply": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "facl_segmax_bwd_apply_amax": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "facl_gemm_fwd": [c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],

@@ -211,7 +211,11 @@ __global__ __launch_bounds__(256) void k_segmax_bwd_stats(const float* __restric
 // 100 MB of fills for 3 MB of values, 15 us -- is not needed.  bnc row 4 = sign(gamma).
 __global__ __launch_bounds__(256) void k_segmax_bwd_stats_ymax(const float* __restrict__ dxpre, const float* __restrict__ xpre,
                                                                const float* __restrict__ ymax, int Mrows, int C,
-                                                               const float* __restrict__ bnc, double* __restrict__ part) {
+                                                               const float* __restrict__ bnc, double* __restrict__ part,
+                                                               unsigned* __restrict__ zamax, int zwords) {
+    // `zamax` (or null): amax words this launch ZEROES for the kernels behind it, which raise them with atomics (spares a fill launch)
+    if (zamax && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < zwords; i += 256) zamax[i] = 0u;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const float mean = bnc[c], inv = bnc[C + c], sg = bnc[4 * C + c];
@@ -584,13 +588,13 @@ extern "C" int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, cons
 }
 
 extern "C" int facl_segmax_bwd_stats_ymax(const float* dxpre, const float* xpre, const float* ymax, int64_t M, int C,
-                                          const float* bnc, double* sums, void* ws, void* stream) {
+                                          const float* bnc, double* sums, void* ws, uint32_t* zamax, int zwords, void* stream) {
     if (!dxpre || !xpre || !ymax || !bnc || !sums || !ws) return FACL_E_NULL;
-    if (M < 1 || M > 0x7fffffff || C < 1 || 2 * C > 4608) return FACL_E_SHAPE;
+    if (M < 1 || M > 0x7fffffff || C < 1 || 2 * C > 4608 || zwords < 0) return FACL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int gy = rows_grid_y((int)M, C);
     hipLaunchKernelGGL(k_segmax_bwd_stats_ymax, dim3((C + 255) / 256, gy), dim3(256), 0, st, dxpre, xpre, ymax, (int)M, C, bnc,
-                       (double*)ws);
+                       (double*)ws, zamax, zwords);
     int rc = facl_launch_status();
     if (rc) return rc;
     return facl_reduce_rows((const double*)ws, gy, 2 * C, sums, st);

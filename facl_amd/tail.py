@@ -778,13 +778,15 @@ class _Net3DV3(torch.autograd.Function):
         dxpre = dxpre.contiguous()
         sums = _lib.empty((C3, 2), **f64)
         # y3 at the argmax = sign(gamma3) * ymax exactly: the sums come from the (M, C3) maxima the forward kept, not from a gather
+        # fp16x3 backward: max|dy| of each of the three gradient tensors, maintained by the kernel that writes it; the words are
+        # zeroed by the statistics launch in front of those kernels (no fill launch)
+        h3 = ctx.bwd_h3 and bp == "f32"
+        amax = _lib.empty((3, _lib.AMAX_WORDS), dtype=torch.int32, device=y1.device) if h3 else None
         _lib.check(lib.facl_segmax_bwd_stats_ymax(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(ymax), M, C3, _lib.ptr(bnc3),
-                                                  _lib.ptr(sums), _lib.ptr(ws), st), "facl_segmax_bwd_stats")
+                                                  _lib.ptr(sums), _lib.ptr(ws), _lib.ptr(amax), 3 * _lib.AMAX_WORDS if h3 else 0, st),
+                   "facl_segmax_bwd_stats")
         dbe3, dga3, kk = _bn_bwd_consts(sums, C3, ctx.count, ctx.reduce_fn)
         dy = _lib.empty_like(y3)
-        # fp16x3 backward: max|dy| of each of the three gradient tensors, maintained by the kernel that writes it
-        h3 = ctx.bwd_h3 and bp == "f32"
-        amax = torch.zeros(3, _lib.AMAX_WORDS, dtype=torch.int32, device=y1.device) if h3 else None
         am = (lambda i: amax[i]) if h3 else (lambda i: None)
         _lib.check(lib.facl_segmax_bwd_apply_amax(_lib.ptr(dxpre), _lib.ptr(xpre), _lib.ptr(y3), _lib.ptr(arg), M, S, C3,
                                                   _lib.ptr(bnc3), _lib.ptr(kk), _lib.ptr(dy), _lib.ptr(am(0)), st),

@@ -258,7 +258,8 @@ int facl_segmax_bwd_stats(const float* dxpre, const float* xpre, const float* y,
 /* the same sums from ymax (M,C) = max over the S rows of sign(gamma)*y, as facl_gemm_rs_fwd / facl_gemm_fwd_segmax return it: the
  * value at the argmax is sign(gamma)*ymax exactly (bnc row 4 holds the sign), so y is not gathered (one cache line per element) */
 int facl_segmax_bwd_stats_ymax(const float* dxpre, const float* xpre, const float* ymax, int64_t M, int C,
-                               const float* bnc, double* sums, void* ws, void* stream);
+                               const float* bnc, double* sums, void* ws, uint32_t* zamax, int zwords, void* stream);
+/* (zamax, zwords: amax words -- or NULL, 0 -- that the call zeroes for the *_amax kernels behind it: spares a fill launch) */
 int facl_segmax_bwd_apply(const float* dxpre, const float* xpre, const float* y, const int32_t* arg,
                           int64_t M, int S, int C, const float* bnc, const float* kk, float* dy, void* stream);
 /* the two dy producers of the BatchNorm backward, also maintaining max|dy| in `amax`: a buffer of FACL_AMAX_WORDS uint32 the

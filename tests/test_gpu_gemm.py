@@ -560,9 +560,11 @@ def test_segmax_bwd_stats_from_kept_maxima_equals_the_gather():
         s2 = _lib.empty(C, 2, dtype=torch.float64, device=DEV)
         _lib.check(lib.facl_segmax_bwd_stats(p(dxpre), p(xpre), p(y), p(arg.contiguous()), Mc, S, C, p(bnc), p(s1), p(_ws()),
                                              _lib.stream()), "segmax_bwd_stats")
+        za = torch.full((5,), -1, dtype=torch.int32, device=DEV)
         _lib.check(lib.facl_segmax_bwd_stats_ymax(p(dxpre), p(xpre), p(ymax.contiguous()), Mc, C, p(bnc), p(s2), p(_ws()),
-                                                  _lib.stream()), "segmax_bwd_stats_ymax")
+                                                  p(za), 4, _lib.stream()), "segmax_bwd_stats_ymax")
         assert torch.equal(s1, s2)
+        assert za.tolist() == [0, 0, 0, 0, -1]                               # the words it is asked to zero, and only those
         assert float(s1.abs().sum()) > 0
 
 
